@@ -1,0 +1,121 @@
+/* zzflate_amd.h -- C ABI of the MI355X-native zzflate encoder path (libzzflate_amd.so).
+ *
+ * Drop-in boundary for jandevaan/zzflate's encoder entry points (reference zzflate/zzflate.h:8-19):
+ *
+ *   reference (C++ linkage)                                   this library
+ *   ---------------------------------------------------------------------------------------------------
+ *   enum Format {Zlib, Gzip, Deflate}          zzflate.h:8     ZZ_ZLIB / ZZ_GZIP / ZZ_DEFLATE (same values)
+ *   struct Config {format; level; threaded}    zzflate.h:10-15 zz_config (same 8-byte layout)
+ *   ZzFlateEncode(dest,&len,src,n,cfg)         zzflate.h:17    zz_encode()            [+ the C++ symbol itself,
+ *   ZzFlateEncodeToCallback(src,n,cfg,fn)      zzflate.h:19    zz_encode_callback()    see include/zzflate.h]
+ *   adler32x / combine                         adler.cpp:5-43  zz_adler32 / zz_adler32_combine
+ *   crc32                                      crc.h:7         zz_crc32 (+ zz_crc32_combine, new)
+ *
+ * Plain pointers and sizes only. The *_device entry points take HIP device pointers (what
+ * torch.Tensor.data_ptr() returns on ROCm) and a hipStream_t passed as void*.
+ *
+ * Semantics: `threaded != 0` selects packet mode = the reference's threaded path (zzflate.cpp:97-155) with
+ * fixed-size ranges ("packets", default 32 KiB) instead of hardware_concurrency() ranges; every packet is
+ * bit-identical to the reference's packet recipe (zzflate.cpp:101-125) wherever that recipe yields a valid
+ * DEFLATE encoding, and always valid otherwise. Inputs no longer than one packet therefore produce exactly
+ * the reference's single-encoder stream. `threaded == 0` with an input longer than one packet asks for the
+ * reference's sequential whole-buffer stream, which is not offered on the device yet: the call fails
+ * (error convention below) instead of falling back to a CPU path.
+ *
+ * Error convention (zzflate.cpp:229-234): *dest_len = ~0 for a bad level or a destination that cannot hold
+ * the container header. This library additionally detects a destination that is too small for the stream
+ * (the reference silently truncates) and reports it the same way. Functions returning int return 0 on
+ * success and a negative ZZ_E_* code otherwise; zz_last_error() gives the message for this thread.
+ */
+#ifndef ZZFLATE_AMD_H
+#define ZZFLATE_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ZZ_ZLIB = 0, ZZ_GZIP = 1, ZZ_DEFLATE = 2 };       /* zzflate.h:8 */
+typedef struct { int32_t format; uint8_t level; uint8_t threaded; } zz_config; /* zzflate.h:10-15, sizeof 8 */
+
+enum {
+    ZZ_OK = 0,
+    ZZ_E_LEVEL = -1,        /* level not in 0..3 (zzflate.cpp:201,230) */
+    ZZ_E_NOSPACE = -2,      /* destination too small */
+    ZZ_E_HIP = -3,          /* HIP runtime error / no device */
+    ZZ_E_ARG = -4,          /* bad argument (packet size, null pointer) */
+    ZZ_E_UNSUPPORTED = -5   /* sequential whole-buffer mode on more than one packet */
+};
+
+#define ZZ_DEFAULT_PACKET 32768u
+#define ZZ_MAX_PACKET_SIZE 32768u
+
+typedef struct zz_ctx zz_ctx;
+
+/* ---- contexts (device, workspace, timing) ------------------------------------------------------- */
+int zz_ctx_create(int device, zz_ctx** out);
+void zz_ctx_destroy(zz_ctx* ctx);
+/* bytes of device workspace currently held */
+uint64_t zz_ctx_workspace_bytes(const zz_ctx* ctx);
+/* record HIP events around the encode kernel of each call; read with zz_ctx_last_kernel_ms */
+void zz_ctx_enable_timing(zz_ctx* ctx, int on);
+/* duration of the last call's dominant (encode) kernel in ms, from HIP events on the launch stream;
+ * negative if timing was off */
+double zz_ctx_last_kernel_ms(zz_ctx* ctx);
+
+/* ---- sizes -------------------------------------------------------------------------------------- */
+/* worst-case output bytes for n input bytes (container included) */
+uint64_t zz_bound(uint64_t n, int format, int level, uint32_t packet_size);
+
+/* ---- host-buffer entry points (drop-in for zzflate.h:17,19) -------------------------------------- */
+/* dest_len: in = capacity, out = bytes written or ~0. Copies through the device of the default context. */
+int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, uint64_t n, const zz_config* cfg);
+/* callback(user, chunk, bytes) is invoked in order: header, stream chunks of <= 1,000,000 bytes
+ * (outputbitstream.h:183), trailer. The callback's return value is ignored, as in the reference. */
+typedef int (*zz_callback)(void* user, const uint8_t* chunk, uint64_t bytes);
+int zz_encode_callback(const uint8_t* src, uint64_t n, const zz_config* cfg, zz_callback cb, void* user);
+/* packet size used by the host entry points (env ZZFLATE_PACKET_SIZE overrides the default) */
+int zz_set_packet_size(uint32_t packet_size);
+uint32_t zz_get_packet_size(void);
+
+/* ---- device-resident entry points ---------------------------------------------------------------- */
+/* Whole stream: d_src[0,n) -> d_dst (container header, packets, trailer). *out_len = bytes or ~0. */
+int zz_encode_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                     int format, int level, uint32_t packet_size, void* hip_stream);
+
+/* One shard of a stream (multi-GPU: ranks own contiguous packet ranges). d_src points at the shard's first
+ * byte; `halo` bytes in front of it are readable input of the same stream (level >= 2 backward match
+ * extension reads up to 258 of them; pass 0 for the first shard). No header/trailer is written; the shard's
+ * checksum partial comes back for zz_adler32_combine / zz_crc32_combine:
+ *   checksum == ZZ_ZLIB: cks = Adler-32 of the shard with start value 0 ((b<<16)|a)
+ *   checksum == ZZ_GZIP: cks = CRC-32 of the shard;   ZZ_DEFLATE: none. */
+int zz_encode_shard_device(zz_ctx* ctx, const void* d_src, uint64_t n, uint64_t halo, int is_last_shard,
+                           void* d_dst, uint64_t cap, uint64_t* out_len, uint32_t* cks, int checksum,
+                           int level, uint32_t packet_size, void* hip_stream);
+
+/* container pieces for assembling shards on the host */
+int zz_header(int format, uint8_t out[10]);                                   /* returns 0/2/10 */
+int zz_trailer(int format, uint32_t cks_total, uint64_t n, uint8_t out[8]);   /* returns 0/4/8  */
+
+/* ---- checksums (host utilities, adler.cpp / crc.cpp semantics) ------------------------------------- */
+uint32_t zz_adler32(uint32_t start, const uint8_t* p, uint64_t n);
+uint32_t zz_adler32_combine(uint32_t first, uint32_t second_start0, uint64_t len_second);
+uint32_t zz_crc32(const uint8_t* p, uint64_t n, uint32_t start);
+uint32_t zz_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
+/* ---- synthetic inputs (BASELINE.json configs), generated on the device ------------------------------ */
+enum { ZZ_GEN_TEXT = 0, ZZ_GEN_RANDOM = 1, ZZ_GEN_LOG = 2, ZZ_GEN_MIX = 3 };
+/* fills d_buf[0,n); byte i is a pure function of (kind, seed, first_byte + i), in 1 MiB blocks */
+int zz_generate_device(zz_ctx* ctx, int kind, uint64_t seed, uint64_t first_byte, void* d_buf, uint64_t n,
+                       void* hip_stream);
+/* the same bytes computed on the host (for parity sampling) */
+int zz_generate_host(int kind, uint64_t seed, uint64_t first_byte, uint8_t* buf, uint64_t n);
+
+const char* zz_last_error(void);
+const char* zz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""The oracle restatement against committed golden vectors (tests/golden/golden.json, produced from the
+compiled reference by tests/golden/make_golden.py) and against zlib's inflate. Runs without the reference."""
+import hashlib
+import json
+import os
+import zlib
+
+import pytest
+
+from conftest import GOLDEN, CORPUS_FILES, synth
+
+G = json.load(open(os.path.join(GOLDEN, "golden.json")))
+WBITS = {0: 15, 1: 31, 2: -15}
+
+
+def h(b):
+    return [len(b), hashlib.sha256(b).hexdigest()]
+
+
+@pytest.mark.parametrize("fname", CORPUS_FILES)
+def test_whole_stream(oracle, corpus, fname):
+    d = corpus[fname]
+    g = G["files"][fname]
+    assert hashlib.sha256(d).hexdigest() == g["sha256"]
+    for fmt in range(3):
+        for lvl in range(4):
+            o = oracle.encode(d, fmt, lvl)
+            assert h(o) == g["whole"][str(fmt)][str(lvl)], (fname, fmt, lvl)
+            assert zlib.decompressobj(WBITS[fmt]).decompress(o) == d
+
+
+@pytest.mark.parametrize("fname", CORPUS_FILES)
+def test_callback_stream(oracle, corpus, fname):
+    d = corpus[fname]
+    for lvl, want in G["files"][fname]["callback"].items():
+        o, sizes = oracle.encode_callback(d, 0, int(lvl))
+        assert h(o) == want[:2] and len(sizes) == want[2]
+        assert sum(sizes) == len(o)
+
+
+@pytest.mark.parametrize("fname", CORPUS_FILES)
+def test_packets(oracle, corpus, fname):
+    d = corpus[fname]
+    for P, per in G["files"][fname]["packets"].items():
+        for lvl, want in per.items():
+            o = oracle.encode_packets(d, 2, int(lvl), int(P))
+            assert h(o) == want, (fname, P, lvl)
+
+
+def test_tiny_exact_bytes(oracle):
+    for name, e in G["tiny"].items():
+        d = bytes.fromhex(e["input_hex"])
+        for key, want in e["whole"].items():
+            fmt, lvl = map(int, key.split("."))
+            assert oracle.encode(d, fmt, lvl).hex() == want, (name, key)
+
+
+def test_synth_packets(oracle):
+    for key, e in G["synth"].items():
+        kind, n = key.split(".")
+        d = synth(kind, int(n), 1)
+        assert hashlib.sha256(d).hexdigest() == e["sha256"]
+        for lvl, want in e["packets"].items():
+            assert h(oracle.encode_packets(d, 2, int(lvl))) == want, (key, lvl)
+
+
+def test_survey_appendix_d(oracle, corpus):
+    """SURVEY.md App. D spot values (sizes + SHA-256 prefixes observed at survey time)."""
+    o = oracle.encode(corpus["alice29.txt"], 0, 1)
+    assert len(o) == 89586 and hashlib.sha256(o).hexdigest().startswith("d6ba1a40e56a")
+    o = oracle.encode(corpus["kennedy.xls"], 0, 2)
+    assert len(o) == 210187 and hashlib.sha256(o).hexdigest().startswith("fb0818dd9444")
+    assert oracle.encode(b"a", 0, 1).hex() == "78014b040000620062"
+    assert oracle.encode(b"a", 0, 0).hex() == "7801010100feff6100620062"
+    assert oracle.encode(corpus["grammar.lsp"], 1, 1)[-8:].hex() == "7d9713d3890e0000"
+    assert len(oracle.encode_packets(corpus["alice29.txt"], 0, 1)) == 92346
+    assert len(oracle.encode_packets(corpus["alice29.txt"], 0, 2)) == 65734
+
+
+def test_d11_long_period_is_valid(oracle):
+    """D11 (found while pinning the oracle): periods >= 259 met with a cold table make the reference emit a
+    distance-0 match; the restatement must still produce a valid stream."""
+    for n in (1000, 5000, 40000):
+        d = synth("longperiod", n, 2)
+        for lvl in (2, 3):
+            for P in (1000, 32768):
+                o = oracle.encode_packets(d, 0, lvl, P)
+                assert zlib.decompress(o) == d
+
+
+def test_bad_level_and_small_dest(oracle):
+    import ctypes
+    assert oracle.encode(b"abc", 0, 4) is None   # zzflate.cpp:230
+    b = ctypes.create_string_buffer(1)
+    assert oracle.L.zzo_encode(b, 1, b"abc", 3, 0, 1) == (1 << 64) - 1   # header does not fit

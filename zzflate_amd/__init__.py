@@ -1,0 +1,231 @@
+"""zzflate_amd -- MI355X-native DEFLATE encoder behind zzflate's entry points.
+
+Host-side mirror of the reference interface (zzflate/zzflate.h:8-19) over the C ABI of
+libzzflate_amd.so (include/zzflate_amd.h). Names follow the reference: ``Format``, ``Config``,
+``ZzFlateEncode``, ``ZzFlateEncodeToCallback``, ``adler32x``, ``combine``, ``crc32``.
+
+There is no CPU encode path: importing works without a GPU (so that the ABI can be inspected), but
+every encode call raises ``ZzFlateError`` when no HIP device is usable.
+"""
+import ctypes
+import enum
+import os
+from dataclasses import dataclass
+
+from . import build as _build
+
+__all__ = [
+    "Format", "Config", "ZzFlateError", "ZzFlateEncode", "ZzFlateEncodeToCallback", "adler32x", "combine",
+    "crc32", "crc32_combine", "bound", "Context", "lib", "DEFAULT_PACKET", "generate_host", "header", "trailer",
+]
+
+DEFAULT_PACKET = 32768
+_ERR = (1 << 64) - 1
+
+
+class Format(enum.IntEnum):  # zzflate.h:8
+    Zlib = 0
+    Gzip = 1
+    Deflate = 2
+
+
+@dataclass
+class Config:  # zzflate.h:10-15
+    format: Format = Format.Zlib
+    level: int = 1
+    threaded: bool = True
+
+
+class _CConfig(ctypes.Structure):
+    _fields_ = [("format", ctypes.c_int32), ("level", ctypes.c_uint8), ("threaded", ctypes.c_uint8)]
+
+
+class ZzFlateError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zzflate_amd error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    path = _build.LIB
+    if not os.path.exists(path):
+        _build.build()
+    L = ctypes.CDLL(path)
+    u64, u32, i32, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
+    pu64 = ctypes.POINTER(ctypes.c_uint64)
+    sig = {
+        "zz_ctx_create": (i32, [i32, ctypes.POINTER(vp)]),
+        "zz_ctx_destroy": (None, [vp]),
+        "zz_ctx_workspace_bytes": (u64, [vp]),
+        "zz_ctx_enable_timing": (None, [vp, i32]),
+        "zz_ctx_last_kernel_ms": (ctypes.c_double, [vp]),
+        "zz_bound": (u64, [u64, i32, i32, u32]),
+        "zz_encode": (i32, [vp, pu64, vp, u64, ctypes.POINTER(_CConfig)]),
+        "zz_encode_callback": (i32, [vp, u64, ctypes.POINTER(_CConfig), vp, vp]),
+        "zz_set_packet_size": (i32, [u32]),
+        "zz_get_packet_size": (u32, []),
+        "zz_encode_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, u32, vp]),
+        "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
+        "zz_header": (i32, [i32, vp]),
+        "zz_trailer": (i32, [i32, u32, u64, vp]),
+        "zz_adler32": (u32, [u32, vp, u64]),
+        "zz_adler32_combine": (u32, [u32, u32, u64]),
+        "zz_crc32": (u32, [vp, u64, u32]),
+        "zz_crc32_combine": (u32, [u32, u32, u64]),
+        "zz_generate_device": (i32, [vp, i32, u64, u64, vp, u64, vp]),
+        "zz_generate_host": (i32, [i32, u64, u64, vp, u64]),
+        "zz_last_error": (ctypes.c_char_p, []),
+        "zz_version": (ctypes.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+lib = _load()
+_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint64)
+
+
+def _check(rc):
+    if rc != 0:
+        raise ZzFlateError(rc, lib.zz_last_error().decode())
+
+
+def _cfg(config):
+    return _CConfig(int(config.format), int(config.level), 1 if config.threaded else 0)
+
+
+def bound(n, format=Format.Zlib, level=1, packet_size=DEFAULT_PACKET):
+    return lib.zz_bound(n, int(format), int(level), packet_size)
+
+
+def ZzFlateEncode(source, config, dest_capacity=None):
+    """zzflate.h:17 -- returns the encoded bytes. ``dest_capacity`` plays the role of ``*destLen`` on
+    entry; a destination that is too small raises (the C entry point sets ``*destLen = ~0``)."""
+    src = bytes(source)
+    cap = bound(len(src), config.format, config.level, lib.zz_get_packet_size()) if dest_capacity is None else dest_capacity
+    dest = ctypes.create_string_buffer(max(cap, 1))
+    n = ctypes.c_uint64(cap)
+    c = _cfg(config)
+    rc = lib.zz_encode(dest, ctypes.byref(n), src, len(src), ctypes.byref(c))
+    _check(rc)
+    return dest.raw[: n.value]
+
+
+def ZzFlateEncodeToCallback(source, config, callback):
+    """zzflate.h:19 -- ``callback(chunk: bytes)`` is called for the header, each stream chunk and the trailer."""
+    src = bytes(source)
+
+    def tramp(_user, ptr, nbytes):
+        callback(ctypes.string_at(ptr, nbytes))
+        return 0
+
+    cb = _CALLBACK(tramp)
+    c = _cfg(config)
+    _check(lib.zz_encode_callback(src, len(src), ctypes.byref(c), ctypes.cast(cb, ctypes.c_void_p), None))
+
+
+def adler32x(start, data):  # adler.cpp:17-43
+    b = bytes(data)
+    return lib.zz_adler32(start, b, len(b))
+
+
+def combine(first, second, len_second):  # adler.cpp:5-15
+    return lib.zz_adler32_combine(first, second, len_second)
+
+
+def crc32(data, start=0):  # crc.h:7
+    b = bytes(data)
+    return lib.zz_crc32(b, len(b), start)
+
+
+def crc32_combine(crc1, crc2, len2):
+    return lib.zz_crc32_combine(crc1, crc2, len2)
+
+
+def header(format):
+    buf = ctypes.create_string_buffer(10)
+    n = lib.zz_header(int(format), buf)
+    return buf.raw[:n]
+
+
+def trailer(format, cks_total, n):
+    buf = ctypes.create_string_buffer(8)
+    k = lib.zz_trailer(int(format), cks_total, n, buf)
+    return buf.raw[:k]
+
+
+def generate_host(kind, seed, first_byte, n):
+    buf = ctypes.create_string_buffer(max(n, 1))
+    _check(lib.zz_generate_host(kind, seed, first_byte, buf, n))
+    return buf.raw[:n]
+
+
+GEN_TEXT, GEN_RANDOM, GEN_LOG, GEN_MIX = 0, 1, 2, 3
+
+
+class Context:
+    """Device context: workspace + timing. Buffers are torch tensors (uint8, on the context's device) or
+    raw device pointers; PyTorch is only the allocator here."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _check(lib.zz_ctx_create(device, ctypes.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib.zz_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptr(t):
+        return t if isinstance(t, int) else t.data_ptr()
+
+    @staticmethod
+    def _stream():
+        try:
+            import torch
+            return torch.cuda.current_stream().cuda_stream
+        except Exception:
+            return 0
+
+    def enable_timing(self, on=True):
+        lib.zz_ctx_enable_timing(self._h, 1 if on else 0)
+
+    def last_kernel_ms(self):
+        return lib.zz_ctx_last_kernel_ms(self._h)
+
+    def workspace_bytes(self):
+        return lib.zz_ctx_workspace_bytes(self._h)
+
+    def encode(self, src, n, dst, cap, format=Format.Zlib, level=1, packet_size=DEFAULT_PACKET, stream=None):
+        """Whole stream on the device; returns the number of bytes written to ``dst``."""
+        out = ctypes.c_uint64(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
+                                    int(level), packet_size, st))
+        return out.value
+
+    def encode_shard(self, src, n, dst, cap, halo=0, is_last=True, checksum=Format.Zlib, level=1,
+                     packet_size=DEFAULT_PACKET, stream=None):
+        """One shard (contiguous packet range) of a stream; returns (bytes, checksum partial)."""
+        out = ctypes.c_uint64(0)
+        cks = ctypes.c_uint32(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_shard_device(self._h, self._ptr(src), n, halo, 1 if is_last else 0, self._ptr(dst), cap,
+                                          ctypes.byref(out), ctypes.byref(cks), int(checksum), int(level), packet_size, st))
+        return out.value, cks.value
+
+    def generate(self, kind, seed, first_byte, buf, n, stream=None):
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_generate_device(self._h, kind, seed, first_byte, self._ptr(buf), n, st))

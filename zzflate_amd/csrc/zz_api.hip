@@ -1,0 +1,473 @@
+// zz_api.hip -- host side of libzzflate_amd.so: contexts, workspaces, kernel launches and the C ABI
+// declared in include/zzflate_amd.h. Mirrors the L4 layer of the reference (zzflate.cpp): container
+// header, range split, fan-out, in-order join, trailer -- with the fan-out being "packets -> wavefronts".
+//
+// There is no CPU encode path in this library: every byte of DEFLATE output is produced by the HIP
+// kernels, and every entry point fails with ZZ_E_HIP when no device is usable.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/zzflate_amd.h"
+#include "zz_common.h"
+#include "zz_wave.h"
+#include "zz_checksum.h"
+#include "zz_emit.h"
+#include "zz_level0.h"
+#include "zz_level1.h"
+#include "zz_level2.h"
+#include "zz_compact.h"
+#include "zz_datagen.h"
+
+using namespace zz;
+
+static thread_local std::string g_err;
+static void set_err(const std::string& s) { g_err = s; }
+extern "C" const char* zz_last_error(void) { return g_err.c_str(); }
+extern "C" const char* zz_version(void) { return "zzflate_amd 0.1 (gfx950)"; }
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            set_err(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+            return ZZ_E_HIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+struct zz_ctx {
+    int device = 0;
+    // workspace (grown on demand, kept across calls so steady-state calls do not allocate)
+    uint8_t* slots = nullptr;   uint64_t slots_cap = 0;
+    uint32_t* sizes = nullptr;  uint64_t* offsets = nullptr;  zz_cks* cks = nullptr;  uint64_t npk_cap = 0;
+    uint8_t* l2_scratch = nullptr; uint64_t l2_scratch_cap = 0;
+    zz_result* d_res = nullptr; zz_cks_total* d_cks_total = nullptr; uint32_t* d_err = nullptr;
+    zz_result* h_res = nullptr;          // pinned
+    // staging for the host-buffer entry points
+    uint8_t* stage_in = nullptr;  uint64_t stage_in_cap = 0;
+    uint8_t* stage_out = nullptr; uint64_t stage_out_cap = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_time = false;
+};
+
+static int header_len(int format) { return format == ZZ_ZLIB ? 2 : format == ZZ_GZIP ? 10 : 0; }
+static int trailer_len(int format) { return format == ZZ_ZLIB ? 4 : format == ZZ_GZIP ? 8 : 0; }
+
+// worst-case bytes one packet can occupy in its slot, per level (multiple of 16)
+static uint32_t slot_stride_for(int level, uint32_t P)
+{
+    uint64_t b;
+    if (level == 0) b = (uint64_t)P + 10;
+    else if (level == 1) b = ((uint64_t)9 * P + 10 + 7) / 8 + 6;   // 3 + 9 bits/byte + EOB, + 1-byte stored block
+    else b = (uint64_t)P + 11;                                      // stored fallback is the worst case
+    b += 8;                                                         // the ring stores whole words
+    return (uint32_t)((b + 15) & ~15ull);
+}
+
+extern "C" uint64_t zz_bound(uint64_t n, int format, int level, uint32_t P)
+{
+    if (P == 0 || P > ZZ_MAX_PACKET_SIZE) P = ZZ_DEFAULT_PACKET;
+    uint64_t npk = n ? (n + P - 1) / P : 1;
+    uint64_t per;
+    if (level == 0) per = (uint64_t)P + 10;
+    else if (level == 1) per = ((uint64_t)9 * P + 10 + 7) / 8 + 6;
+    else per = (uint64_t)P + 11;
+    return header_len(format) + npk * per + trailer_len(format) + 16;
+}
+
+extern "C" int zz_ctx_create(int device, zz_ctx** out)
+{
+    if (!out) { set_err("null out"); return ZZ_E_ARG; }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) { set_err("no HIP device available: this library has no CPU encode path"); return ZZ_E_HIP; }
+    if (device < 0 || device >= count) { set_err("bad device index"); return ZZ_E_ARG; }
+    HIPCHK(hipSetDevice(device));
+    zz_ctx* c = new zz_ctx();
+    c->device = device;
+    HIPCHK(hipMalloc(&c->d_res, sizeof(zz_result)));
+    HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
+    HIPCHK(hipMalloc(&c->d_err, sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    *out = c;
+    return ZZ_OK;
+}
+
+extern "C" void zz_ctx_destroy(zz_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
+    (void)hipFree(c->l2_scratch);
+    (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err);
+    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out);
+    (void)hipHostFree(c->h_res);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+extern "C" uint64_t zz_ctx_workspace_bytes(const zz_ctx* c)
+{
+    if (!c) return 0;
+    return c->slots_cap + c->npk_cap * (4 + 8 + sizeof(zz_cks)) + c->l2_scratch_cap + c->stage_in_cap + c->stage_out_cap;
+}
+extern "C" void zz_ctx_enable_timing(zz_ctx* c, int on) { if (c) { c->timing = on != 0; c->have_time = false; } }
+extern "C" double zz_ctx_last_kernel_ms(zz_ctx* c)
+{
+    if (!c || !c->timing || !c->have_time) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+    return ms;
+}
+
+static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
+{
+    if (npk > c->npk_cap) {
+        (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
+        c->sizes = nullptr; c->offsets = nullptr; c->cks = nullptr; c->npk_cap = 0;
+        HIPCHK(hipMalloc(&c->sizes, npk * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->offsets, npk * sizeof(uint64_t)));
+        HIPCHK(hipMalloc(&c->cks, npk * sizeof(zz_cks)));
+        c->npk_cap = npk;
+    }
+    if (level != 0) {
+        uint64_t need = npk * stride;
+        if (need > c->slots_cap) {
+            (void)hipFree(c->slots); c->slots = nullptr; c->slots_cap = 0;
+            HIPCHK(hipMalloc(&c->slots, need));
+            c->slots_cap = need;
+        }
+    }
+    if (level >= 2) {
+        uint64_t need = npk * (uint64_t)ZZ_L2_SCRATCH_BYTES;
+        if (need > c->l2_scratch_cap) {
+            (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
+            HIPCHK(hipMalloc(&c->l2_scratch, need));
+            c->l2_scratch_cap = need;
+        }
+    }
+    return ZZ_OK;
+}
+
+// The common pipeline. with_container: write header/trailer (whole stream) or not (shard).
+static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t halo, bool last_is_final,
+                         uint8_t* d_dst, uint64_t cap, int format, int cks_kind, bool with_container, int level,
+                         uint32_t P, hipStream_t st, zz_result* host_res)
+{
+    if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
+    if (P == 0 || P > ZZ_MAX_PACKET_SIZE) { set_err("packet size must be 1..32768"); return ZZ_E_ARG; }
+    if (!d_dst || (!d_src && n)) { set_err("null buffer"); return ZZ_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const int hl = with_container ? header_len(format) : 0;
+    const int tl = with_container ? trailer_len(format) : 0;
+    if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
+    const uint64_t npk64 = (n + P - 1) / P;
+    if (npk64 > 0x7FFFFFFFull) { set_err("too many packets for one call"); return ZZ_E_ARG; }
+    const uint32_t npk = (uint32_t)npk64;
+    const uint32_t stride = slot_stride_for(level, P);
+    c->have_time = false;
+
+    HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(zz_result), st));
+    HIPCHK(hipMemsetAsync(c->d_cks_total, 0, sizeof(zz_cks_total), st));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), st));
+
+    if (npk == 0) {
+        // empty input: the reference emits no block at all, which is not a valid stream;
+        // emit one empty final block instead (stored at level 0, fixed otherwise)
+        uint8_t blk[5]; uint32_t bl;
+        if (!last_is_final) bl = 0;
+        else if (level == 0) { blk[0] = 1; blk[1] = 0; blk[2] = 0; blk[3] = 0xFF; blk[4] = 0xFF; bl = 5; }
+        else { blk[0] = 0x03; blk[1] = 0x00; bl = 2; }
+        if ((uint64_t)hl + bl + tl > cap) { set_err("destination too small"); return ZZ_E_NOSPACE; }
+        if (bl) HIPCHK(hipMemcpyAsync(d_dst + hl, blk, bl, hipMemcpyHostToDevice, st));
+        zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = bl;
+        HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
+    } else {
+        int rc = ensure_workspace(c, level, npk, stride);
+        if (rc) return rc;
+        zz_packet_params pp;
+        pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
+        pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind;
+        pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err;
+
+        if (cks_kind == ZZ_CKS_CRC) {
+            uint32_t g = npk < 65536 ? npk : 65536;
+            hipLaunchKernelGGL(k_crc32_packets, dim3(g), dim3(ZZ_CRC_THREADS), 0, st, pp);
+            pp.cks_kind = ZZ_CKS_NONE;   // the encode kernel must not overwrite the CRC partials
+        }
+        if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));
+        if (level == 0) {
+            const uint64_t total = (uint64_t)(npk - 1) * l0_packet_bytes(P, false) +
+                                   l0_packet_bytes((uint32_t)(n - (uint64_t)(npk - 1) * P), last_is_final);
+            if ((uint64_t)hl + total + tl > cap) { set_err("destination too small"); return ZZ_E_NOSPACE; }
+            zz_l0_params q; q.pk = pp; q.dst = d_dst + hl;
+            uint32_t g = npk < 16384 ? npk : 16384;
+            hipLaunchKernelGGL(k_encode_l0, dim3(g), dim3(256), 0, st, q);
+            zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
+            HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
+        } else if (level == 1) {
+            hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_WAVE), 0, st, pp);
+        } else {
+            launch_level2(pp, c->l2_scratch, st);
+        }
+        if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
+        if (level != 0) {
+            hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(ZZ_SCAN_THREADS), 0, st, c->sizes, npk, c->offsets, c->d_res);
+            uint32_t g = npk < 65536 ? npk : 65536;
+            hipLaunchKernelGGL(k_compact, dim3(g), dim3(256), 0, st, c->slots, stride, c->sizes, c->offsets, npk,
+                               d_dst + hl, cap >= (uint64_t)(hl + tl) ? cap - hl - tl : 0, c->d_res);
+        }
+        if (cks_kind != ZZ_CKS_NONE)
+            hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk, P, n, cks_kind, c->d_cks_total);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, d_dst, cap, with_container ? format : (int)ZZ_FMT_DEFLATE,
+                       c->d_cks_total, n, c->d_res);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(zz_result), hipMemcpyDeviceToHost, st));
+    uint32_t kerr = 0;
+    HIPCHK(hipMemcpyAsync(&kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *host_res = *c->h_res;
+    if (kerr) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
+    if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    return ZZ_OK;
+}
+
+static int cks_kind_for(int format) { return format == ZZ_ZLIB ? ZZ_CKS_ADLER : format == ZZ_GZIP ? ZZ_CKS_CRC : ZZ_CKS_NONE; }
+
+extern "C" int zz_encode_device(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                                int format, int level, uint32_t P, void* hip_stream)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;   // zzflate.cpp:39-48 default branch
+    if (P == 0) P = ZZ_DEFAULT_PACKET;
+    zz_result r;
+    int rc = encode_common(c, (const uint8_t*)d_src, n, 0, true, (uint8_t*)d_dst, cap, format, cks_kind_for(format),
+                           true, level, P, (hipStream_t)hip_stream, &r);
+    if (rc) return rc;
+    *out_len = r.total_bytes;
+    return ZZ_OK;
+}
+
+extern "C" int zz_encode_shard_device(zz_ctx* c, const void* d_src, uint64_t n, uint64_t halo, int is_last, void* d_dst,
+                                      uint64_t cap, uint64_t* out_len, uint32_t* cks, int checksum, int level,
+                                      uint32_t P, void* hip_stream)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
+    if (P == 0) P = ZZ_DEFAULT_PACKET;
+    zz_result r;
+    int rc = encode_common(c, (const uint8_t*)d_src, n, halo, is_last != 0, (uint8_t*)d_dst, cap, ZZ_DEFLATE,
+                           cks_kind_for(checksum), false, level, P, (hipStream_t)hip_stream, &r);
+    if (rc) return rc;
+    *out_len = r.stream_bytes;
+    if (cks) *cks = checksum == ZZ_ZLIB ? ((r.cks_b << 16) | r.cks_a) : r.cks_a;
+    return ZZ_OK;
+}
+
+// ---- container pieces --------------------------------------------------------------------------------
+extern "C" int zz_header(int format, uint8_t out[10])
+{
+    static const uint8_t gz[10] = { 0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xFF };   // zzflate.cpp:28
+    if (format == ZZ_ZLIB) { out[0] = 0x78; out[1] = 0x01; return 2; }          // zzflate.cpp:30-36
+    if (format == ZZ_GZIP) { memcpy(out, gz, 10); return 10; }
+    return 0;
+}
+extern "C" int zz_trailer(int format, uint32_t v, uint64_t n, uint8_t out[8])   // zzflate.cpp:170-192
+{
+    if (format == ZZ_ZLIB) { out[0] = v >> 24; out[1] = v >> 16; out[2] = v >> 8; out[3] = v; return 4; }
+    if (format == ZZ_GZIP) {
+        uint32_t l = (uint32_t)n;
+        for (int i = 0; i < 4; ++i) { out[i] = (uint8_t)(v >> (8 * i)); out[4 + i] = (uint8_t)(l >> (8 * i)); }
+        return 8;
+    }
+    return 0;
+}
+
+// ---- host checksum utilities (adler.cpp / crc.cpp API; not on the encode path) ----------------------------
+extern "C" uint32_t zz_adler32(uint32_t start, const uint8_t* p, uint64_t n)
+{
+    uint64_t a = start & 0xFFFF, b = start >> 16;
+    while (n) {
+        uint64_t k = n < 5552 ? n : 5552;
+        for (uint64_t i = 0; i < k; ++i) { a += p[i]; b += a; }
+        a %= ZZ_ADLER_MOD; b %= ZZ_ADLER_MOD;
+        p += k; n -= k;
+    }
+    return (uint32_t)((b << 16) | a);
+}
+extern "C" uint32_t zz_adler32_combine(uint32_t first, uint32_t second, uint64_t len2) { return adler_combine(first, second, len2); }
+extern "C" uint32_t zz_crc32(const uint8_t* p, uint64_t n, uint32_t start)
+{
+    static uint32_t tab[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int j = 0; j < 8; ++j) c = (c >> 1) ^ ((c & 1u) * ZZ_CRC_POLY);
+            tab[i] = c;
+        }
+    });
+    uint32_t c = ~start;
+    for (uint64_t i = 0; i < n; ++i) c = (c >> 8) ^ tab[(c & 0xFF) ^ p[i]];
+    return ~c;
+}
+extern "C" uint32_t zz_crc32_combine(uint32_t c1, uint32_t c2, uint64_t len2) { return crc32_combine(c1, c2, len2); }
+
+// ---- default context + host-buffer entry points ------------------------------------------------------------
+static std::mutex g_mu;
+static zz_ctx* g_default = nullptr;
+static uint32_t g_packet = 0;
+
+extern "C" uint32_t zz_get_packet_size(void)
+{
+    if (g_packet == 0) {
+        const char* e = getenv("ZZFLATE_PACKET_SIZE");
+        long v = e ? atol(e) : 0;
+        g_packet = (v >= 1 && v <= (long)ZZ_MAX_PACKET_SIZE) ? (uint32_t)v : ZZ_DEFAULT_PACKET;
+    }
+    return g_packet;
+}
+extern "C" int zz_set_packet_size(uint32_t P)
+{
+    if (P == 0 || P > ZZ_MAX_PACKET_SIZE) { set_err("packet size must be 1..32768"); return ZZ_E_ARG; }
+    g_packet = P;
+    return ZZ_OK;
+}
+
+static int default_ctx(zz_ctx** out)
+{
+    if (!g_default) {
+        const char* e = getenv("ZZFLATE_DEVICE");
+        int rc = zz_ctx_create(e ? atoi(e) : 0, &g_default);
+        if (rc) return rc;
+    }
+    *out = g_default;
+    return ZZ_OK;
+}
+
+static int ensure_stage(zz_ctx* c, uint64_t in_bytes, uint64_t out_bytes)
+{
+    if (in_bytes > c->stage_in_cap) {
+        (void)hipFree(c->stage_in); c->stage_in = nullptr; c->stage_in_cap = 0;
+        HIPCHK(hipMalloc(&c->stage_in, in_bytes + 64));
+        c->stage_in_cap = in_bytes + 64;
+    }
+    if (out_bytes > c->stage_out_cap) {
+        (void)hipFree(c->stage_out); c->stage_out = nullptr; c->stage_out_cap = 0;
+        HIPCHK(hipMalloc(&c->stage_out, out_bytes + 64));
+        c->stage_out_cap = out_bytes + 64;
+    }
+    return ZZ_OK;
+}
+
+// shared by zz_encode / zz_encode_callback: compress host src into the context's device staging buffer
+static int encode_host_to_stage(zz_ctx* c, const uint8_t* src, uint64_t n, const zz_config* cfg, uint64_t* total)
+{
+    const int level = cfg->level;
+    if (level < 0 || level > 3) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
+    const uint32_t P = zz_get_packet_size();
+    if (!cfg->threaded && n > P) {
+        set_err("threaded=false (sequential whole-buffer stream) is only available for inputs of at most one "
+                "packet on the device; use threaded=true");
+        return ZZ_E_UNSUPPORTED;
+    }
+    int format = cfg->format;
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    const uint64_t bound = zz_bound(n, format, level, P);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_stage(c, n, bound);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpy(c->stage_in, src, n, hipMemcpyHostToDevice));
+    return zz_encode_device(c, c->stage_in, n, c->stage_out, bound, total, format, level, P, nullptr);
+}
+
+extern "C" int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, uint64_t n, const zz_config* cfg)
+{
+    if (!dest_len) { set_err("null dest_len"); return ZZ_E_ARG; }
+    const uint64_t cap = *dest_len;
+    *dest_len = ~0ull;
+    if (!cfg || !dest) { set_err("null argument"); return ZZ_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    zz_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    if (cap < (uint64_t)header_len(cfg->format)) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
+    uint64_t total = 0;
+    rc = encode_host_to_stage(c, src, n, cfg, &total);
+    if (rc) return rc;
+    if (total > cap) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    HIPCHK(hipMemcpy(dest, c->stage_out, total, hipMemcpyDeviceToHost));
+    *dest_len = total;
+    return ZZ_OK;
+}
+
+extern "C" int zz_encode_callback(const uint8_t* src, uint64_t n, const zz_config* cfg, zz_callback cb, void* user)
+{
+    if (!cfg || !cb) { set_err("null argument"); return ZZ_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    zz_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    uint64_t total = 0;
+    rc = encode_host_to_stage(c, src, n, cfg, &total);
+    if (rc) return rc;
+    std::vector<uint8_t> host(total);
+    if (total) HIPCHK(hipMemcpy(host.data(), c->stage_out, total, hipMemcpyDeviceToHost));
+    int format = cfg->format;
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    const uint64_t hl = header_len(format), tl = trailer_len(format);
+    // zzflate.cpp:204-221: header, then the stream in library-owned chunks, then the trailer
+    cb(user, host.data(), hl);
+    uint64_t pos = hl, end = total - tl;
+    while (pos < end) {
+        uint64_t k = end - pos < 1000000 ? end - pos : 1000000;   // outputbitstream.h:183
+        cb(user, host.data() + pos, k);
+        pos += k;
+    }
+    cb(user, host.data() + end, tl);
+    return ZZ_OK;
+}
+
+// ---- synthetic inputs -----------------------------------------------------------------------------------------
+__global__ void k_generate(int kind, uint64_t seed, uint64_t first_block, uint8_t* buf, uint64_t n)
+{
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t off = b * ZZ_GEN_BLOCK;
+    if (off >= n) return;
+    uint32_t cap = (uint32_t)(n - off < ZZ_GEN_BLOCK ? n - off : ZZ_GEN_BLOCK);
+    zzgen::gen_block(kind, seed, first_block + b, buf + off, cap);
+}
+
+extern "C" int zz_generate_device(zz_ctx* c, int kind, uint64_t seed, uint64_t first_byte, void* d_buf, uint64_t n,
+                                  void* hip_stream)
+{
+    if (!c || !d_buf) { set_err("null argument"); return ZZ_E_ARG; }
+    if (first_byte % ZZ_GEN_BLOCK) { set_err("first_byte must be a multiple of 65536"); return ZZ_E_ARG; }
+    if (n == 0) return ZZ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    uint64_t nb = (n + ZZ_GEN_BLOCK - 1) / ZZ_GEN_BLOCK;
+    hipLaunchKernelGGL(k_generate, dim3((uint32_t)((nb + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, kind, seed,
+                       first_byte / ZZ_GEN_BLOCK, (uint8_t*)d_buf, n);
+    HIPCHK(hipGetLastError());
+    return ZZ_OK;
+}
+extern "C" int zz_generate_host(int kind, uint64_t seed, uint64_t first_byte, uint8_t* buf, uint64_t n)
+{
+    if (!buf) { set_err("null argument"); return ZZ_E_ARG; }
+    if (first_byte % ZZ_GEN_BLOCK) { set_err("first_byte must be a multiple of 65536"); return ZZ_E_ARG; }
+    for (uint64_t off = 0; off < n; off += ZZ_GEN_BLOCK) {
+        uint32_t cap = (uint32_t)(n - off < ZZ_GEN_BLOCK ? n - off : ZZ_GEN_BLOCK);
+        zzgen::gen_block(kind, seed, (first_byte + off) / ZZ_GEN_BLOCK, buf + off, cap);
+    }
+    return ZZ_OK;
+}

@@ -1,0 +1,185 @@
+// zz_checksum.h -- Adler-32 and CRC-32 as per-packet partials plus order-preserving combines.
+//
+// Replaces zzflate.cpp:170-192 (AppendChecksum), adler.cpp:5-43 and crc.cpp:5-33: the reference makes a
+// second scalar pass over the whole input; here every packet's partial is produced by the wave that
+// encodes the packet (Adler, fused into the encode kernels) or by a sibling kernel (CRC), and partials
+// are folded in packet order with `combine` semantics (adler.cpp:5-15) / GF(2) polynomial shifts.
+#pragma once
+#include "zz_wave.h"
+
+#define ZZ_ADLER_MOD 65521u
+#define ZZ_CRC_POLY 0xEDB88320u
+
+namespace zz {
+
+// ---- GF(2) helpers (host + device) ------------------------------------------------------------------
+// a(x)*b(x) mod P(x), bit-reflected representation (bit 31 = x^0)
+__host__ __device__ inline uint32_t gf2_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ ZZ_CRC_POLY : b >> 1;
+    }
+    return p;
+}
+// x^(8*nbytes) mod P
+__host__ __device__ inline uint32_t gf2_xpow8(uint64_t nbytes)
+{
+    uint32_t r = 0x80000000u;   // x^0
+    uint32_t sq = 0x00800000u;  // x^8
+    for (; nbytes; nbytes >>= 1) {
+        if (nbytes & 1) r = gf2_mulmod(r, sq);
+        sq = gf2_mulmod(sq, sq);
+    }
+    return r;
+}
+// crc(A||B) from the finished CRC-32s of A and B and |B|
+__host__ __device__ inline uint32_t crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    return gf2_mulmod(crc1, gf2_xpow8(len2)) ^ crc2;
+}
+// adler.cpp:5-15: `second` computed with start value 0
+__host__ __device__ inline uint32_t adler_combine(uint32_t first, uint32_t second, uint64_t len2)
+{
+    uint64_t a = (uint64_t)(first & 0xFFFF) + (second & 0xFFFF);
+    uint64_t b = (uint64_t)(first >> 16) + (second >> 16) + (len2 % ZZ_ADLER_MOD) * (first & 0xFFFF);
+    return (uint32_t)(((b % ZZ_ADLER_MOD) << 16) | (a % ZZ_ADLER_MOD));
+}
+
+// ---- Adler-32 partial of one packet, one wavefront ----------------------------------------------------
+// Returns (a, b) for start value 0: a = sum d_i, b = sum (len - i) d_i, both mod 65521. 16 bytes per lane
+// per step, coalesced; len <= 32768 so 64-bit accumulators cannot overflow.
+__device__ __forceinline__ zz_cks wave_adler(const uint8_t* p, uint32_t len)
+{
+    const int lane = lane_id();
+    uint32_t A = 0;
+    uint64_t C = 0;  // sum i * d_i
+    const uint32_t nchunks = len >> 4;
+    for (uint32_t c = lane; c < nchunks; c += ZZ_WAVE) {
+        uint4 v;
+        __builtin_memcpy(&v, p + ((uint64_t)c << 4), 16);
+        uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, 0u), s1 = __builtin_amdgcn_sad_u8(v.y, 0u, 0u);
+        uint32_t s2 = __builtin_amdgcn_sad_u8(v.z, 0u, 0u), s3 = __builtin_amdgcn_sad_u8(v.w, 0u, 0u);
+        // sum k*b_k inside each dword (k = 0..3)
+        auto w3 = [](uint32_t x) { return ((x >> 8) & 0xFF) + 2 * ((x >> 16) & 0xFF) + 3 * (x >> 24); };
+        uint32_t t = w3(v.x) + (w3(v.y) + 4 * s1) + (w3(v.z) + 8 * s2) + (w3(v.w) + 12 * s3);
+        uint32_t s = s0 + s1 + s2 + s3;
+        A += s;
+        C += (uint64_t)(c << 4) * s + t;
+    }
+    uint32_t i = (nchunks << 4) + lane;
+    if (i < len) {
+        uint32_t d = p[i];
+        A += d;
+        C += (uint64_t)i * d;
+    }
+    uint64_t At = wave_sum64(A);
+    uint64_t Ct = wave_sum64(C);
+    zz_cks r;
+    r.a = (uint32_t)(At % ZZ_ADLER_MOD);
+    r.b = (uint32_t)(((uint64_t)len * At - Ct) % ZZ_ADLER_MOD);
+    return r;
+}
+
+// ---- CRC-32 per packet (sibling kernel; gzip container only) ------------------------------------------
+// 256 threads per packet; each thread runs slicing-by-4 over a contiguous slice from LDS tables, then the
+// packet CRC is the XOR over threads of crc_t * x^(8 * bytes after slice t).
+#define ZZ_CRC_THREADS 256
+__global__ __launch_bounds__(ZZ_CRC_THREADS) void k_crc32_packets(zz_packet_params P)
+{
+    __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t red[ZZ_CRC_THREADS / ZZ_WAVE];
+    const uint32_t tid = threadIdx.x;
+    {
+        uint32_t c = tid;
+        for (int j = 0; j < 8; ++j) c = (c >> 1) ^ ((c & 1u) * ZZ_CRC_POLY);   // crc.cpp:5-20
+        tab[0][tid] = c;
+    }
+    __syncthreads();
+    for (int t = 1; t < 4; ++t) {
+        uint32_t c = tab[t - 1][tid];
+        tab[t][tid] = (c >> 8) ^ tab[0][c & 0xFF];
+    }
+    __syncthreads();
+    for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
+        const uint64_t off = (uint64_t)k * P.packet_size;
+        const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
+        const uint8_t* p = P.src + off;
+        const uint32_t slice = ((len + ZZ_CRC_THREADS - 1) / ZZ_CRC_THREADS + 3) & ~3u;
+        uint32_t b0 = tid * slice, b1 = b0 + slice;
+        if (b0 > len) b0 = len;
+        if (b1 > len) b1 = len;
+        uint32_t c = 0;
+        if (b1 > b0) {
+            c = ~0u;
+            uint32_t i = b0;
+            for (; i + 4 <= b1; i += 4) {
+                c ^= load32(p + i);
+                c = tab[3][c & 0xFF] ^ tab[2][(c >> 8) & 0xFF] ^ tab[1][(c >> 16) & 0xFF] ^ tab[0][c >> 24];
+            }
+            for (; i < b1; ++i) c = (c >> 8) ^ tab[0][(c & 0xFF) ^ p[i]];   // crc.cpp:28-31
+            c = ~c;
+            c = gf2_mulmod(c, gf2_xpow8(len - b1));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c ^= __shfl_xor(c, o);
+        if ((tid & 63) == 0) red[tid >> 6] = c;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t r = 0;
+            for (int w = 0; w < ZZ_CRC_THREADS / ZZ_WAVE; ++w) r ^= red[w];
+            P.cks[k].a = r;
+            P.cks[k].b = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- fold the per-packet partials of a shard into one (in packet order) --------------------------------
+// One workgroup; thread t folds a contiguous run of packets, then thread 0 folds the 1024 runs.
+struct zz_cks_total { uint32_t a, b; uint64_t len; };
+#define ZZ_RED_THREADS 1024
+__global__ __launch_bounds__(ZZ_RED_THREADS) void k_cks_reduce(const zz_cks* cks, uint32_t npk, uint32_t packet_size,
+                                                               uint64_t n, int kind, zz_cks_total* out)
+{
+    __shared__ uint32_t sa[ZZ_RED_THREADS], sb[ZZ_RED_THREADS];
+    __shared__ uint64_t sl[ZZ_RED_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (npk + ZZ_RED_THREADS - 1) / ZZ_RED_THREADS;
+    uint32_t k0 = t * per, k1 = k0 + per;
+    if (k0 > npk) k0 = npk;
+    if (k1 > npk) k1 = npk;
+    uint64_t a = 0, b = 0, len = 0;
+    const uint32_t xp = kind == ZZ_CKS_CRC ? gf2_xpow8(packet_size) : 0;
+    for (uint32_t k = k0; k < k1; ++k) {
+        uint64_t off = (uint64_t)k * packet_size;
+        uint64_t l = (n - off) < packet_size ? (n - off) : packet_size;
+        if (kind == ZZ_CKS_ADLER) {
+            b = (b + cks[k].b + (l % ZZ_ADLER_MOD) * a) % ZZ_ADLER_MOD;
+            a = (a + cks[k].a) % ZZ_ADLER_MOD;
+        } else {
+            uint32_t sh = l == packet_size ? xp : gf2_xpow8(l);
+            a = gf2_mulmod((uint32_t)a, sh) ^ cks[k].a;
+        }
+        len += l;
+    }
+    sa[t] = (uint32_t)a; sb[t] = (uint32_t)b; sl[t] = len;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t A = 0, B = 0, L = 0;
+        for (uint32_t i = 0; i < ZZ_RED_THREADS; ++i) {
+            if (sl[i] == 0) continue;
+            if (kind == ZZ_CKS_ADLER) {
+                B = (B + sb[i] + (sl[i] % ZZ_ADLER_MOD) * A) % ZZ_ADLER_MOD;
+                A = (A + sa[i]) % ZZ_ADLER_MOD;
+            } else {
+                A = gf2_mulmod((uint32_t)A, gf2_xpow8(sl[i])) ^ sa[i];
+            }
+            L += sl[i];
+        }
+        out->a = (uint32_t)A; out->b = (uint32_t)B; out->len = L;
+    }
+}
+
+}  // namespace zz

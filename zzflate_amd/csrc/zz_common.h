@@ -1,0 +1,37 @@
+// zz_common.h -- shared constants and launch-parameter structs for the MI355X DEFLATE encoder.
+//
+// Vocabulary follows the reference (jandevaan/zzflate): a *packet* is one independently encoded input
+// range (the lambda at zzflate.cpp:101-125); its output is a byte-aligned run of complete DEFLATE blocks,
+// so packet outputs concatenate by plain byte copy (zzflate.cpp:134-155). One packet = one wavefront.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZZ_WAVE 64
+#define ZZ_HASH_BITS 13                 // encoder.h:41
+#define ZZ_HASH_SIZE (1 << ZZ_HASH_BITS)
+#define ZZ_MAX_LEN 258                  // encoder.h:47
+#define ZZ_MAX_PACKET 32768             // positions fit 15 bits -> u16 table entries (pos+1, 0 = empty)
+#define ZZ_BATCH_LEN 16384              // encoder.cpp:227
+
+enum { ZZ_FMT_ZLIB = 0, ZZ_FMT_GZIP = 1, ZZ_FMT_DEFLATE = 2 };   // zzflate.h:8
+enum { ZZ_CKS_NONE = 0, ZZ_CKS_ADLER = 1, ZZ_CKS_CRC = 2 };
+
+// Per-packet checksum partial. Adler: (a, b) of the packet computed with start value 0
+// (adler.cpp:5-15 `combine` semantics). CRC: a = crc32 of the packet with start value 0, b unused.
+struct zz_cks { uint32_t a, b; };
+
+struct zz_packet_params {
+    const uint8_t* src;       // first byte of this shard
+    uint64_t n;               // shard length in bytes
+    uint64_t halo;            // readable bytes in front of src (level >= 2 backward extension, encoder.cpp:404)
+    uint32_t packet_size;     // bytes per packet (last one may be shorter)
+    uint32_t npk;             // number of packets in the shard
+    int last_is_final;        // last packet of the shard carries BFINAL
+    int cks_kind;             // ZZ_CKS_*
+    uint8_t* slots;           // npk worst-case sized output slots
+    uint32_t slot_stride;     // bytes per slot (multiple of 16)
+    uint32_t* sizes;          // out: bytes written per packet
+    zz_cks* cks;              // out: checksum partial per packet (may be null when cks_kind == NONE)
+    uint32_t* err;            // out: sticky error word (slot overflow etc.)
+};

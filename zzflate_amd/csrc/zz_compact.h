@@ -1,0 +1,86 @@
+// zz_compact.h -- in-order join of packet outputs: prefix sum of packet sizes, byte compaction, and the
+// container header/trailer. Replaces the serial memmove join of zzflate.cpp:134-155 and the header /
+// trailer writers (zzflate.cpp:28-63, :170-192).
+#pragma once
+#include "zz_checksum.h"
+
+namespace zz {
+
+struct zz_result {
+    uint64_t stream_bytes;   // compacted DEFLATE bytes (no header/trailer)
+    uint64_t total_bytes;    // header + stream + trailer (0 for shard calls)
+    uint32_t err;            // 0 ok; bit0 slot overflow, bit1 destination too small
+    uint32_t cks_a, cks_b;   // shard checksum partial (start value 0 semantics)
+    uint64_t cks_len;
+};
+
+#define ZZ_SCAN_THREADS 1024
+// exclusive prefix sum of sizes[0..npk) into offsets; total to res->stream_bytes. One workgroup.
+__global__ __launch_bounds__(ZZ_SCAN_THREADS) void k_scan_sizes(const uint32_t* sizes, uint32_t npk,
+                                                                uint64_t* offsets, zz_result* res)
+{
+    __shared__ uint64_t part[ZZ_SCAN_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (npk + ZZ_SCAN_THREADS - 1) / ZZ_SCAN_THREADS;
+    uint32_t k0 = t * per, k1 = k0 + per;
+    if (k0 > npk) k0 = npk;
+    if (k1 > npk) k1 = npk;
+    uint64_t s = 0;
+    for (uint32_t k = k0; k < k1; ++k) s += sizes[k];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele over 1024 partials
+    for (uint32_t d = 1; d < ZZ_SCAN_THREADS; d <<= 1) {
+        uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t base = t ? part[t - 1] : 0;
+    for (uint32_t k = k0; k < k1; ++k) { offsets[k] = base; base += sizes[k]; }
+    if (t == ZZ_SCAN_THREADS - 1) res->stream_bytes = part[t];
+}
+
+// copy every packet's bytes from its slot to dst + offsets[k]; skipped entirely if the destination is too
+// small (err bit1; the reference would silently truncate)
+__global__ __launch_bounds__(256) void k_compact(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes,
+                                                 const uint64_t* offsets, uint32_t npk, uint8_t* dst,
+                                                 uint64_t dst_cap, zz_result* res)
+{
+    if (res->stream_bytes > dst_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&res->err, 2u);
+        return;
+    }
+    for (uint32_t k = blockIdx.x; k < npk; k += gridDim.x)
+        coop_copy(dst + offsets[k], slots + (uint64_t)k * slot_stride, sizes[k], threadIdx.x, blockDim.x);
+}
+
+// header (zzflate.cpp:28-48) + trailer (zzflate.cpp:170-192) around a finished stream; one thread.
+//   zlib : 78 01 ... adler32x(1, src, n) big-endian
+//   gzip : 1f 8b 08 00 00000000 00 ff ... crc32 LE, (uint32)n LE
+__global__ void k_finalize(uint8_t* dst, uint64_t cap, int format, const zz_cks_total* cks, uint64_t n, zz_result* res)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t hl = format == ZZ_FMT_ZLIB ? 2 : format == ZZ_FMT_GZIP ? 10 : 0;
+    const uint32_t tl = format == ZZ_FMT_ZLIB ? 4 : format == ZZ_FMT_GZIP ? 8 : 0;
+    const uint64_t total = hl + res->stream_bytes + tl;
+    if (cks) { res->cks_a = cks->a; res->cks_b = cks->b; res->cks_len = cks->len; }
+    if (res->err || total > cap) { res->err |= 2u; res->total_bytes = 0; return; }
+    if (format == ZZ_FMT_ZLIB) {
+        dst[0] = 0x78; dst[1] = 0x01;
+        uint32_t part = ((uint32_t)cks->b << 16) | cks->a;
+        uint32_t ad = adler_combine(1u, part, n);
+        uint8_t* t = dst + hl + res->stream_bytes;
+        t[0] = (uint8_t)(ad >> 24); t[1] = (uint8_t)(ad >> 16); t[2] = (uint8_t)(ad >> 8); t[3] = (uint8_t)ad;
+    } else if (format == ZZ_FMT_GZIP) {
+        const uint8_t gz[10] = { 0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xFF };
+        for (int i = 0; i < 10; ++i) dst[i] = gz[i];
+        uint8_t* t = dst + hl + res->stream_bytes;
+        uint32_t c = cks->a, l = (uint32_t)n;
+        t[0] = (uint8_t)c; t[1] = (uint8_t)(c >> 8); t[2] = (uint8_t)(c >> 16); t[3] = (uint8_t)(c >> 24);
+        t[4] = (uint8_t)l; t[5] = (uint8_t)(l >> 8); t[6] = (uint8_t)(l >> 16); t[7] = (uint8_t)(l >> 24);
+    }
+    res->total_bytes = total;
+}
+
+}  // namespace zz

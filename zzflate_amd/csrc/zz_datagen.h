@@ -1,0 +1,205 @@
+// zz_datagen.h -- counter-based synthetic inputs for BASELINE.json's configs.
+//
+// Block b (64 KiB) of a stream is a pure function of (kind, seed, b): the device fills HBM without PCIe
+// traffic (one thread per block) and the host can regenerate any slice for parity sampling. Integer
+// arithmetic only, so host and device agree bit for bit.
+//   TEXT   "enwik-style": Zipf-like words over a 65,536-word seeded vocabulary, punctuation, newlines,
+//          some <tag>/[[link]] markup                                    (config 2)
+//   RANDOM splitmix64 bytes, incompressible                              (config 3)
+//   LOG    timestamped log lines from 4,096 seeded templates             (config 5)
+//   MIX    64 KiB segments cycling through text / log / random / binary records / DNA / gradients (config 4)
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define ZZ_GEN_BLOCK 65536u
+
+namespace zzgen {
+
+__host__ __device__ inline uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct rng { uint64_t s; };
+__host__ __device__ inline uint64_t next(rng& r) { r.s += 0x9E3779B97F4A7C15ull; return mix64(r.s); }
+
+struct sink { uint8_t* p; uint32_t n, cap; };
+__host__ __device__ inline void put(sink& o, uint8_t c) { if (o.n < o.cap) o.p[o.n] = c; o.n++; }
+
+__host__ __device__ inline uint8_t letter(uint32_t h)
+{
+    // 64 letters, roughly English frequencies
+    const char* L = "eeeeeeeetttttaaaaaoooooiiiiinnnnssssshhhhrrrrdddlllccuummwwffggyp";
+    return (uint8_t)L[h & 63];
+}
+// Zipf-like rank in [0, 65535]: uniform octave, uniform inside the octave
+__host__ __device__ inline uint32_t zipf_rank(uint64_t u)
+{
+    uint32_t k = (uint32_t)(u & 15);
+    uint32_t r = (uint32_t)(u >> 8);
+    return ((1u << k) | (r & ((1u << k) - 1))) - 1;
+}
+__host__ __device__ inline void put_word(sink& o, uint64_t seed, uint32_t rank, bool cap)
+{
+    uint64_t h = mix64(seed * 0x100000001B3ull + rank);
+    uint32_t oct = 32 - (uint32_t)__builtin_clz(rank + 1);        // 1..16
+    uint32_t len = 1 + oct / 3 + (uint32_t)(h & 3) + ((h >> 2) & 1);   // frequent words are short
+    h >>= 3;
+    for (uint32_t i = 0; i < len; ++i) {
+        if ((i & 7) == 7) h = mix64(h + i);
+        uint8_t c = letter((uint32_t)h);
+        h >>= 6;
+        if (cap && i == 0) c = (uint8_t)(c - 32);
+        put(o, c);
+    }
+}
+__host__ __device__ inline void put_dec(sink& o, uint32_t v, int width)
+{
+    char tmp[10];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v && n < 10);
+    for (int i = n; i < width; ++i) put(o, '0');
+    while (n) put(o, (uint8_t)tmp[--n]);
+}
+
+__host__ __device__ inline void gen_text(sink& o, uint64_t seed, uint64_t block)
+{
+    rng r{ mix64(seed ^ (block * 0xD1342543DE82EF95ull)) };
+    uint32_t col = 0, wrap = 60 + (uint32_t)(next(r) % 40);
+    bool cap = true;
+    while (o.n < o.cap) {
+        uint64_t u = next(r);
+        uint32_t start = o.n;
+        uint32_t sel = (uint32_t)(u >> 40) & 63;
+        if (sel == 0) {            // <tag> word </tag>
+            put(o, '<'); put_word(o, seed, zipf_rank(u) & 255, false); put(o, '>');
+            put_word(o, seed, zipf_rank(next(r)), false);
+            put(o, '<'); put(o, '/'); put_word(o, seed, zipf_rank(u) & 255, false); put(o, '>');
+        } else if (sel == 1) {     // [[link]]
+            put(o, '['); put(o, '['); put_word(o, seed, zipf_rank(u), true); put(o, ']'); put(o, ']');
+        } else if (sel == 2) {     // a number
+            put_dec(o, (uint32_t)(u >> 20) % 3000, 1);
+        } else {
+            put_word(o, seed, zipf_rank(u), cap);
+        }
+        cap = false;
+        uint32_t q = (uint32_t)(u >> 48) & 31;
+        if (q == 0) { put(o, '.'); cap = true; }
+        else if (q < 3) put(o, ',');
+        col += o.n - start + 1;
+        if (col >= wrap) { put(o, '\n'); col = 0; wrap = 60 + (uint32_t)(next(r) % 40); }
+        else put(o, ' ');
+    }
+}
+
+__host__ __device__ inline void gen_random(sink& o, uint64_t seed, uint64_t block)
+{
+    uint64_t base = block * (ZZ_GEN_BLOCK / 8);
+    for (uint32_t i = 0; i < o.cap; i += 8) {
+        uint64_t v = mix64(seed + (base + i / 8) * 0x9E3779B97F4A7C15ull);
+        for (uint32_t j = 0; j < 8 && i + j < o.cap; ++j) o.p[i + j] = (uint8_t)(v >> (8 * j));
+    }
+    o.n = o.cap;
+}
+
+__host__ __device__ inline void gen_log(sink& o, uint64_t seed, uint64_t block)
+{
+    rng r{ mix64(seed ^ (block * 0xA0761D6478BD642Full)) };
+    // monotone timestamps: ~600 lines per block, 1..50 ms apart
+    uint64_t ms = block * 20000ull;
+    const char* levels[4] = { "INFO", "INFO", "WARN", "ERROR" };
+    while (o.n < o.cap) {
+        uint64_t u = next(r);
+        ms += 1 + (u & 31);
+        uint32_t sec = (uint32_t)(ms / 1000), day = sec / 86400;
+        uint32_t sod = sec % 86400;
+        put_dec(o, 2026, 4); put(o, '-'); put_dec(o, 1 + (day / 28) % 12, 2); put(o, '-'); put_dec(o, 1 + day % 28, 2);
+        put(o, 'T'); put_dec(o, sod / 3600, 2); put(o, ':'); put_dec(o, (sod / 60) % 60, 2); put(o, ':');
+        put_dec(o, sod % 60, 2); put(o, '.'); put_dec(o, (uint32_t)(ms % 1000), 3); put(o, 'Z'); put(o, ' ');
+        const char* hs = "host-";
+        for (int i = 0; hs[i]; ++i) put(o, (uint8_t)hs[i]);
+        put_dec(o, (uint32_t)(u >> 8) & 63, 2); put(o, ' ');
+        uint32_t tmpl = zipf_rank(u >> 16) & 4095;
+        put_word(o, seed ^ 0x5EC, tmpl & 31, false);            // service name
+        put(o, '['); put_dec(o, 1000 + ((tmpl * 7919u) % 30000), 1); put(o, ']'); put(o, ':'); put(o, ' ');
+        const char* lv = levels[(u >> 30) & 3];
+        for (int i = 0; lv[i]; ++i) put(o, (uint8_t)lv[i]);
+        put(o, ' ');
+        uint64_t th = mix64(seed + tmpl);
+        uint32_t nw = 3 + (uint32_t)(th & 7);
+        for (uint32_t i = 0; i < nw; ++i) {                      // the template's fixed words
+            put_word(o, seed, (uint32_t)(mix64(th + i) & 2047), false);
+            put(o, ' ');
+        }
+        uint32_t nkv = 1 + (uint32_t)((th >> 8) & 3);
+        for (uint32_t i = 0; i < nkv; ++i) {                     // k=v with varying values
+            put_word(o, seed, (uint32_t)(mix64(th + 100 + i) & 255), false);
+            put(o, '=');
+            put_dec(o, (uint32_t)(next(r) >> 40) % 100000, 1);
+            put(o, i + 1 < nkv ? ' ' : '\n');
+        }
+    }
+}
+
+__host__ __device__ inline void gen_records(sink& o, uint64_t seed, uint64_t block)   // kennedy.xls-like
+{
+    rng r{ mix64(seed ^ (block * 0x8EBC6AF09C88C6E3ull)) };
+    uint32_t row = (uint32_t)(block * 1000);
+    while (o.n < o.cap) {
+        uint64_t u = next(r);
+        put(o, 0x7E); put(o, 0x02); put(o, 0x0A); put(o, 0x00);
+        put(o, (uint8_t)row); put(o, (uint8_t)(row >> 8)); put(o, (uint8_t)(u & 15)); put(o, 0);
+        put(o, 0x0F); put(o, 0x00);
+        uint32_t v = (uint32_t)(u >> 16) % 5000;
+        put(o, (uint8_t)v); put(o, (uint8_t)(v >> 8)); put(o, 0); put(o, 0x40);
+        if ((u & 15) == 15) row++;
+    }
+}
+__host__ __device__ inline void gen_dna(sink& o, uint64_t seed, uint64_t block)
+{
+    rng r{ mix64(seed ^ (block * 0x589965CC75374CC3ull)) };
+    const char* b = "ACGT";
+    while (o.n < o.cap) {
+        uint64_t u = next(r);
+        for (int i = 0; i < 32; ++i) { put(o, (uint8_t)b[u & 3]); u >>= 2; }
+    }
+}
+__host__ __device__ inline void gen_gradient(sink& o, uint64_t seed, uint64_t block)   // 16-bit noisy ramp
+{
+    rng r{ mix64(seed ^ (block * 0x1D8E4E27C47D124Full)) };
+    uint32_t v = (uint32_t)(block * 37) & 0xFFFF;
+    while (o.n < o.cap) {
+        uint64_t u = next(r);
+        for (int i = 0; i < 16; ++i) {
+            v = (v + 3 + (uint32_t)(u & 3)) & 0xFFFF;
+            u >>= 4;
+            put(o, (uint8_t)v); put(o, (uint8_t)(v >> 8));
+        }
+    }
+}
+
+__host__ __device__ inline void gen_block(int kind, uint64_t seed, uint64_t block, uint8_t* dst, uint32_t cap)
+{
+    sink o{ dst, 0, cap };
+    switch (kind) {
+    case 0: gen_text(o, seed, block); break;
+    case 1: gen_random(o, seed, block); break;
+    case 2: gen_log(o, seed, block); break;
+    default: {
+        // 16 MiB segments (256 blocks) cycling through six generators
+        switch ((block >> 8) % 6) {
+        case 0: gen_text(o, seed, block); break;
+        case 1: gen_log(o, seed, block); break;
+        case 2: gen_records(o, seed, block); break;
+        case 3: gen_random(o, seed, block); break;
+        case 4: gen_dna(o, seed, block); break;
+        default: gen_gradient(o, seed, block); break;
+        }
+    }
+    }
+}
+
+}  // namespace zzgen

@@ -1,0 +1,110 @@
+// zz_wave.h -- wavefront (64-lane) primitives for gfx950: ballots, DPP prefix scans, uniform reads,
+// bounds-safe unaligned loads, and a wave-cooperative byte copy.
+#pragma once
+#include "zz_common.h"
+
+namespace zz {
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ uint32_t readlane(uint32_t v, int l)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l));
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
+{
+    uint32_t lo = readlane((uint32_t)v, l), hi = readlane((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ---- DPP scans --------------------------------------------------------------------------------
+// update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes whose source lane is outside
+// the row (or masked off) keep `old`; with old = 0 that is the additive identity.
+#define ZZ_DPP_ROW_SHR(n) (0x110 + (n))
+#define ZZ_DPP_ROW_BCAST15 0x142
+#define ZZ_DPP_ROW_BCAST31 0x143
+
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, ZZ_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, ZZ_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, ZZ_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, ZZ_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, ZZ_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, ZZ_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return (uint32_t)v;
+}
+
+// wave-wide sums (result valid in every lane)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+{
+    return readlane(wave_scan_incl(x), 63);
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+// ---- loads ------------------------------------------------------------------------------------
+// gfx950 runs with unaligned global access enabled (amdhsa), so a byte-addressed 4/8-byte load is one
+// global_load_dword/dwordx2. `end` is one past the last readable byte: a load that would cross it is
+// assembled byte-wise and zero-padded (only the tail of the last packet ever takes that path).
+__device__ __forceinline__ uint64_t load64(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint32_t load32(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t load64_safe(const uint8_t* p, const uint8_t* end)
+{
+    if (p + 8 <= end) return load64(p);
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i)
+        if (p + i < end) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ uint32_t load32_safe(const uint8_t* p, const uint8_t* end)
+{
+    if (p + 4 <= end) return load32(p);
+    uint32_t v = 0;
+    for (int i = 0; i < 4; ++i)
+        if (p + i < end) v |= (uint32_t)p[i] << (8 * i);
+    return v;
+}
+
+// ---- cooperative byte copy ------------------------------------------------------------------------
+// Copies n bytes src -> dst with `nthreads` threads (tid in [0,nthreads)); dst and src may have any
+// alignment. Stores are 16-byte aligned dwordx4, loads are byte-addressed dwordx4.
+__device__ __forceinline__ void coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t tid,
+                                          uint32_t nthreads)
+{
+    if (n == 0) return;
+    uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+    if (head > n) head = n;
+    if (tid < head) dst[tid] = src[tid];
+    uint64_t body = (n - head) >> 4;
+    const uint8_t* s = src + head;
+    uint4* d = (uint4*)(dst + head);
+    for (uint64_t i = tid; i < body; i += nthreads) {
+        uint4 v;
+        __builtin_memcpy(&v, s + (i << 4), 16);
+        d[i] = v;
+    }
+    uint64_t done = head + (body << 4);
+    uint64_t tail = n - done;
+    if (tid < tail) dst[done + tid] = src[done + tid];
+}
+
+}  // namespace zz
