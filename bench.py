@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the zzflate encoder hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--mib M] [--gen text|random|log|mix]
+
+A *step* is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+each rank compresses its own contiguous shard of packets (BASELINE.json configs[1]: 1 GiB of synthetic
+"enwik-style" text per GPU, level 1, zlib container, 32 KiB packets) into a device buffer, then -- for
+N > 1 -- the per-rank sizes/checksums are all-gathered and the compressed shards are gathered onto rank 0
+with one grouped RCCL send/recv (the "single gather over xGMI" of the north star). `value` is whole-job
+input GB/s = bytes all ranks compressed / max-over-ranks time. Scaling is weak (fixed work per GPU).
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  "roofline":     the encode kernel's algorithmic bytes (input read once + compressed bytes written once,
+                  SURVEY.md 8d) over its mean launch duration measured with HIP events on the launch stream,
+                  against the 8 TB/s HBM peak; "traffic" comes from profiles/traffic.json when present
+  "cpu_baseline": the unmodified reference (oracle/_ref, kind "reference") or, if that build is absent, the
+                  oracle restatement (kind "port"), timed on this box's host cores on a bounded sample.
+The oracle is only the checker / baseline here, never the thing measured.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GEN = {"text": 0, "random": 1, "log": 2, "mix": 3}
+SEEDS = {"text": 0x5EED0002, "random": 0x5EED0003, "mix": 0x5EED0004, "log": 0x5EED0005}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample: bytes, level: int, fmt: int):
+    """Time the reference's CPU encoder (threaded=false per thread, one thread per host core, each on its own
+    slice of the sample). Returns the cpu_baseline JSON object."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libzzref.so")
+    slice_bytes = 32 << 20
+    nslices = max(1, len(sample) // slice_bytes)
+    rounds = max(1, (4 * cores) // nslices)   # every core gets ~4 slices => ~15-25 s of CPU work in total
+    u64, ci, vp = ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p
+    if os.path.exists(ref_path):
+        L = ctypes.CDLL(ref_path)
+        fn = L.zzref_encode_inplace
+        fn.restype = u64
+        fn.argtypes = [vp, u64, vp, u64, ci, ci, ci]
+        kind = "reference"
+
+        def run(dst, cap, src_ptr, n):
+            return fn(dst, cap, src_ptr, n, fmt, level, 0)
+    else:
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libzzoracle.so"))
+        fn = L.zzo_encode
+        fn.restype = u64
+        fn.argtypes = [vp, u64, vp, u64, ci, ci]
+        kind = "port"
+
+        def run(dst, cap, src_ptr, n):
+            return fn(dst, cap, src_ptr, n, fmt, level)
+    buf = ctypes.create_string_buffer(sample, len(sample) + 64)   # >= 8 readable bytes after the data
+    base = ctypes.addressof(buf)
+    outs = [ctypes.create_string_buffer(2 * slice_bytes + 1024) for _ in range(min(cores, nslices))]
+    todo = list(range(nslices)) * rounds
+    lock = threading.Lock()
+    produced = [0]
+
+    def worker(w):
+        while True:
+            with lock:
+                if not todo:
+                    return
+                s = todo.pop()
+            r = run(outs[w], 2 * slice_bytes + 1024, base + s * slice_bytes, slice_bytes)
+            with lock:
+                produced[0] += r
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(len(outs))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    total = nslices * rounds * slice_bytes
+    return {
+        "value": round(total / dt / 1e9, 4), "unit": "GB/s", "cores": len(outs), "kind": kind,
+        "sample": f"{nslices * rounds} x {slice_bytes >> 20} MiB slices ({nslices} distinct) of the same input, level {level}, one "
+                  f"ZzFlateEncode(threaded=false) call per slice, one thread per core; ratio {produced[0] / total:.4f}; "
+                  f"{dt:.2f} s wall",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--mib", type=int, default=1024, help="input MiB per GPU")
+    ap.add_argument("--gen", default="text", choices=list(GEN))
+    ap.add_argument("--format", default="zlib", choices=["zlib", "gzip", "deflate"])
+    ap.add_argument("--packet", type=int, default=32768)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
+    args = ap.parse_args()
+
+    import torch
+    import zzflate_amd as zz
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dev = local if world > 1 else 0
+    torch.cuda.set_device(dev)
+    fmt = {"zlib": 0, "gzip": 1, "deflate": 2}[args.format]
+    ctx = zz.Context(dev)
+    ctx.enable_timing(True)
+
+    n = args.mib << 20                 # bytes per rank (weak scaling)
+    total_n = n * world
+    P = args.packet
+    src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate(GEN[args.gen], SEEDS[args.gen], rank * n, src, n)     # rank r holds bytes [r*n, (r+1)*n)
+    cap = zz.bound(n, 2, args.level, P)
+    shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
+    meta = torch.zeros(2, dtype=torch.int64, device="cuda")
+    metas = torch.zeros(2 * world, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+
+    kernel_ms = []
+    state = {}
+
+    def step():
+        if world == 1:
+            w = ctx.encode(src, n, shard, cap, fmt, args.level, P)
+            state["out_bytes"] = w
+            state["comp_bytes"] = w
+        else:
+            w, cks = ctx.encode_shard(src, n, shard, cap, halo=0, is_last=(rank == world - 1), checksum=fmt,
+                                      level=args.level, packet_size=P)
+            meta[0], meta[1] = w, cks
+            dist.all_gather_into_tensor(metas, meta)
+            m = metas.cpu().tolist()
+            sizes, ckss = m[0::2], m[1::2]
+            # one grouped send/recv: every rank's compressed shard lands at its final offset on rank 0
+            hl = len(zz.header(fmt))
+            ops, off = [], hl
+            for r in range(world):
+                if rank == 0 and r != 0:
+                    ops.append(dist.P2POp(dist.irecv, gathered[off:off + sizes[r]], r))
+                elif rank == r and r != 0:
+                    ops.append(dist.P2POp(dist.isend, shard[:sizes[r]], 0))
+                off += sizes[r]
+            if rank == 0:
+                gathered[hl:hl + sizes[0]].copy_(shard[:sizes[0]])
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            if rank == 0:
+                tot = 1 if fmt == 0 else 0
+                for r in range(world):
+                    tot = zz.combine(tot, ckss[r], n) if fmt == 0 else (zz.crc32_combine(tot, ckss[r], n) if fmt == 1 else 0)
+                head, tail = zz.header(fmt), zz.trailer(fmt, tot, total_n)
+                if head:
+                    gathered[:hl].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
+                if tail:
+                    gathered[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
+                state["out_bytes"] = off + len(tail)
+            state["comp_bytes"] = w
+        kernel_ms.append(ctx.last_kernel_ms())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- validation of what was just measured (untimed): inflate a prefix, check sizes -------------------
+    check = {}
+    if rank == 0:
+        import zlib
+        out_t = shard if world == 1 else gathered
+        k = min(state["out_bytes"], 96 << 20)
+        head = out_t[:k].cpu().numpy().tobytes()
+        o = zlib.decompressobj({0: 15, 1: 31, 2: -15}[fmt])
+        dec = o.decompress(head, 64 << 20)
+        ref = src[:len(dec)].cpu().numpy().tobytes() if len(dec) <= n else None
+        check["inflate_prefix_ok"] = bool(ref is not None and dec == ref)
+        check["inflate_prefix_bytes"] = len(dec)
+
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra and args.level == 1:
+        # the config's "dynamic Huffman" wording means reference level 2: side measurement
+        try:
+            cap2 = zz.bound(n, fmt, 2, P)
+            dst2 = torch.empty(cap2, dtype=torch.uint8, device="cuda")
+            w2 = ctx.encode(src, n, dst2, cap2, fmt, 2, P)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                w2 = ctx.encode(src, n, dst2, cap2, fmt, 2, P)
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t2) / reps
+            extra["level2"] = {"value": round(n / d2 / 1e9, 3), "unit": "GB/s", "ratio": round(w2 / n, 4),
+                               "kernel_ms": round(ctx.last_kernel_ms(), 3)}
+            del dst2
+        except Exception as e:   # level 2 not available yet
+            extra["level2"] = {"error": str(e)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        sample_bytes = min(n, 1 << 30)
+        cpu = cpu_baseline(src[:sample_bytes].cpu().numpy().tobytes(), args.level, fmt)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        kms = sum(kernel_ms) / max(1, len(kernel_ms))
+        comp = state["comp_bytes"]
+        algo_bytes = n + comp                      # per launch on this rank: input once + compressed once
+        achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"level{args.level}_{args.gen}_{args.mib}MiB")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "input GB/s compressed (whole node) + ratio, level 1, 1/2/4/8 MI355X",
+            "value": round(total_n * args.steps / dt / 1e9, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "ratio": round(state["out_bytes"] / total_n, 4),
+            "config": {
+                "workload": f"{args.mib} MiB synthetic {args.gen} per GPU (zz_generate_device kind={args.gen}, seed "
+                            f"{SEEDS[args.gen]:#x}), level {args.level}, {args.format} container, {P}-byte packets, "
+                            f"input and output resident in HBM" + (", shards gathered to rank 0 over RCCL" if world > 1 else ""),
+                "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": f"k_encode_l{min(args.level, 2)}",
+                "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4), "traffic": traffic,
+            },
+            "cpu_baseline": cpu,
+            "check": check,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,13 @@ class ZzFlateError(RuntimeError):
 
 
 def _load():
+    # PyTorch wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7). Two
+    # HIP runtimes in one process do not work ("no ROCm-capable device"), so when torch is installed it is
+    # imported first: the library's NEEDED libamdhip64.so.7 then binds to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.LIB
     if not os.path.exists(path):
         _build.build()

@@ -85,7 +85,11 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
     if (!out) { set_err("null out"); return ZZ_E_ARG; }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0) { set_err("no HIP device available: this library has no CPU encode path"); return ZZ_E_HIP; }
+    if (e != hipSuccess || count == 0) {
+        set_err(std::string("no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(e) + ", count " +
+                std::to_string(count) + "): this library has no CPU encode path");
+        return ZZ_E_HIP;
+    }
     if (device < 0 || device >= count) { set_err("bad device index"); return ZZ_E_ARG; }
     HIPCHK(hipSetDevice(device));
     zz_ctx* c = new zz_ctx();
@@ -147,7 +151,7 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
         }
     }
     if (level >= 2) {
-        uint64_t need = npk * (uint64_t)ZZ_L2_SCRATCH_BYTES;
+        uint64_t need = (uint64_t)l2_grid((uint32_t)npk) * ZZ_L2_SCRATCH_BYTES;
         if (need > c->l2_scratch_cap) {
             (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
             HIPCHK(hipMalloc(&c->l2_scratch, need));

@@ -1,11 +1,611 @@
-// zz_level2.h -- placeholder until the level >= 2 kernels land: flags an error instead of encoding.
+// zz_level2.h -- levels 2 and 3 (one code path in the reference, encoder.cpp:506-527): two-pass dynamic
+// Huffman, one packet per wavefront.
+//
+// Restates WriteBlock2Pass (encoder.cpp:217-303) for a packet (zzflate.cpp:101-125), bit-exact:
+//
+//   token pass   FirstPass + AddHashEntries (encoder.cpp:375-440, 474-480). At this level EVERY position a
+//                match covers is inserted, in ascending order, so the candidate a probe at j sees is simply
+//                "the previous position with the same 13-bit hash" -- independent of the parse (SURVEY.md 7,
+//                hard part 2). The wave therefore inserts aligned blocks of 64 positions at once (LDS table
+//                as pos+1, one read/write/read-back round trip, ballot loop over the hashes that occur more
+//                than once in the block) and gets all 64 candidates in registers; only the greedy choice
+//                "first probe position whose forward+backward match is >= 4" is serial, and it runs as a
+//                ballot walk inside the block. Exact lengths (forward up to 258, backward up to the pending
+//                literal count) are measured by the whole wave, 4 bytes per lane, for the chosen probe only.
+//                The two positions the reference never inserts (packet byte 0 and the first byte of a batch
+//                that the previous batch did not overrun, encoder.cpp:383,435-436) are skipped.
+//   histograms   GetFrequencies (encoder.cpp:442-471): per-position status bitmaps (covered / match start)
+//                make this and the emission pass parallel over positions; counts via LDS atomics.
+//   code build   CalcLengths (huffman.cpp:122-154): heap Huffman + frequency-floor length limit. Code lengths
+//                depend on libstdc++'s make_heap/pop_heap/push_heap element movements (ties!), so lane 0
+//                replays bits/stl_heap.h (GCC 11: __push_heap :134-148, __adjust_heap :223-248) on LDS arrays.
+//                huffman::generate (huffman.h:49-81) and FromLengths (huffman.cpp:158-216) follow.
+//   emission     dynamic header (encoder.cpp:280-293: always 286/30/19 codes), body (WriteRecords :149-169
+//                with merged length codes :121-133), or UncompressedFallback (:305-317) when the dynamic block
+//                would not be smaller (:271-274).
 #pragma once
-#include "zz_common.h"
-#define ZZ_L2_SCRATCH_BYTES 16
+#include "zz_checksum.h"
+#include "zz_emit.h"
+#include "zz_level1.h"
+
 namespace zz {
-__global__ void k_l2_unimplemented(zz_packet_params P) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(P.err, 4u); }
-static inline void launch_level2(const zz_packet_params& pp, uint8_t*, hipStream_t st)
+
+struct l2_token { uint16_t start, dist, len, pad; };
+#define ZZ_L2_MAX_TOKENS 8192                       // every match covers >= 4 bytes of a <= 32768-byte packet
+#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 8)  // per resident workgroup
+#define ZZ_L2_BLOCKS (ZZ_MAX_PACKET / 64)           // 512 aligned position blocks per packet
+
+// ---- 64-bit fragments through the bit ring ----------------------------------------------------------------
+__device__ __forceinline__ void ring_flush_all_full(bitring& r)
 {
-    hipLaunchKernelGGL(k_l2_unimplemented, dim3(1), dim3(64), 0, st, pp);
+    while ((r.bitpos >> 5) > r.flushed) {
+        const uint32_t full = r.bitpos >> 5;
+        const uint32_t upto = full - r.flushed > 64 ? r.flushed + 64 : full;
+        __syncthreads();
+        const uint32_t w = r.flushed + lane_id();
+        if (w < upto) {
+            uint32_t v = r.ring[w & (ZZ_RING_WORDS - 1)];
+            r.ring[w & (ZZ_RING_WORDS - 1)] = 0;
+            r.out32[w] = v;
+        }
+        r.flushed = upto;
+        __syncthreads();
+    }
 }
+// every lane appends nb <= 48 bits (so one append adds at most 96 words; the ring holds 128)
+__device__ __forceinline__ void ring_append64(bitring& r, uint64_t bits, uint32_t nb)
+{
+    const uint32_t incl = wave_scan_incl(nb);
+    const uint32_t total = readlane(incl, 63);
+    const uint32_t o = r.bitpos + incl - nb;
+    const uint32_t sh = o & 31;
+    const uint32_t w = o >> 5;
+    if (nb) {
+        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+        atomicOr(&r.ring[w & (ZZ_RING_WORDS - 1)], lo << sh);
+        if (sh + nb > 32) {
+            const uint32_t w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh);
+            atomicOr(&r.ring[(w + 1) & (ZZ_RING_WORDS - 1)], w1);
+            if (sh + nb > 64) atomicOr(&r.ring[(w + 2) & (ZZ_RING_WORDS - 1)], sh ? hi >> (32 - sh) : 0u);
+        }
+    }
+    r.bitpos += total;
+    ring_flush_all_full(r);
 }
+
+// ---- Huffman code construction (lane 0, LDS scratch) ---------------------------------------------------------
+struct huff_scratch {
+    uint32_t* rec_freq;   // [288] heap records: frequency            (huffman.h:10-14)
+    uint16_t* rec_id;     // [288]               tree index
+    uint32_t* t_freq;     // [576] tree items                          (huffman.h:16-22)
+    uint16_t* t_left;     // [576] leaf: symbol; internal: left child
+    uint16_t* t_right;    // [576] 0xFFFF for a leaf
+    uint8_t* t_bits;      // [576]
+};
+
+// bits/stl_heap.h __push_heap with comparator `greater` on frequency (huffman.cpp:55-62)
+__device__ __forceinline__ void heap_push(huff_scratch& S, int hole, int top, uint32_t vf, uint16_t vi)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && S.rec_freq[parent] > vf) {
+        S.rec_freq[hole] = S.rec_freq[parent];
+        S.rec_id[hole] = S.rec_id[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    S.rec_freq[hole] = vf;
+    S.rec_id[hole] = vi;
+}
+// bits/stl_heap.h __adjust_heap
+__device__ __forceinline__ void heap_adjust(huff_scratch& S, int hole, int len, uint32_t vf, uint16_t vi)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (S.rec_freq[child] > S.rec_freq[child - 1]) child--;
+        S.rec_freq[hole] = S.rec_freq[child];
+        S.rec_id[hole] = S.rec_id[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        S.rec_freq[hole] = S.rec_freq[child - 1];
+        S.rec_id[hole] = S.rec_id[child - 1];
+        hole = child - 1;
+    }
+    heap_push(S, hole, top, vf, vi);
+}
+
+// huffman.cpp:67-120 CalculateTree; returns the maximum leaf depth
+__device__ inline int calculate_tree(huff_scratch& S, const uint32_t* freqs, int n, uint32_t minFreq, int* ntree)
+{
+    int nrec = 0, nt = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t f = freqs[i];
+        if (f != 0) {
+            if (f < minFreq) f = minFreq;
+            S.rec_freq[nrec] = f;
+            S.rec_id[nrec] = (uint16_t)i;
+            nrec++;
+        }
+        S.t_freq[nt] = f; S.t_left[nt] = (uint16_t)i; S.t_right[nt] = 0xFFFF; S.t_bits[nt] = 0;
+        nt++;
+    }
+    // make_heap (stl_heap.h:339-360)
+    if (nrec >= 2) {
+        for (int parent = (nrec - 2) / 2;; --parent) {
+            heap_adjust(S, parent, nrec, S.rec_freq[parent], S.rec_id[parent]);
+            if (parent == 0) break;
+        }
+    }
+    while (nrec >= 2) {
+        // pop_heap (stl_heap.h:253-265): last element becomes the value sifted from the root
+        uint32_t af = S.rec_freq[0]; uint16_t ai = S.rec_id[0];
+        nrec--;
+        if (nrec >= 1) heap_adjust(S, 0, nrec, S.rec_freq[nrec], S.rec_id[nrec]);
+        uint32_t bf = S.rec_freq[0]; uint16_t bi = S.rec_id[0];
+        nrec--;
+        if (nrec >= 1) heap_adjust(S, 0, nrec, S.rec_freq[nrec], S.rec_id[nrec]);
+        const uint32_t sum = af + bf;
+        S.t_freq[nt] = sum; S.t_left[nt] = ai; S.t_right[nt] = bi; S.t_bits[nt] = 0;
+        nrec++;
+        heap_push(S, nrec - 1, 0, sum, (uint16_t)nt);
+        nt++;
+    }
+    int maxLength = 0;
+    for (int i = nt - 1; i != 0; --i) {                      // huffman.cpp:108, index 0 skipped
+        if (S.t_right[i] == 0xFFFF) { if (S.t_bits[i] > maxLength) maxLength = S.t_bits[i]; continue; }
+        const uint8_t b = (uint8_t)(S.t_bits[i] + 1);
+        S.t_bits[S.t_left[i]] = b;
+        S.t_bits[S.t_right[i]] = b;
+    }
+    *ntree = nt;
+    return maxLength;
+}
+
+// huffman.cpp:122-154 CalcLengths
+__device__ inline void calc_lengths(huff_scratch& S, const uint32_t* freqs, int n, int maxlen, uint8_t* out)
+{
+    uint32_t minFreq = 0;
+    int nt = 0;
+    for (;;) {
+        const int mx = calculate_tree(S, freqs, n, minFreq, &nt);
+        if (mx <= maxlen) {
+            for (int i = 0; i < n; ++i)   // leaves are tree items 0..n-1 in symbol order
+                out[i] = S.t_freq[i] == 0 ? 0 : (S.t_bits[i] > 1 ? S.t_bits[i] : 1);
+            return;
+        }
+        uint32_t total = 0;
+        for (int i = 0; i < n; ++i) total += freqs[i];
+        const uint32_t step = total >> maxlen;
+        minFreq += step > 1 ? step : 1;
+    }
+}
+
+// huffman.h:49-81 generate: canonical codes, stored bit-reversed, packed (len << 16) | bits; 0 for unused.
+// work: 32 words of LDS (bl_count[16], next_code[16]) -- runtime-indexed private arrays would go to scratch.
+__device__ inline void generate_codes(const uint8_t* lengths, int n, uint32_t* codes, uint32_t* work)
+{
+    uint32_t* bl_count = work;
+    uint32_t* next_code = work + 16;
+    for (int b = 0; b < 16; ++b) bl_count[b] = 0;
+    for (int i = 0; i < n; ++i) bl_count[lengths[i]]++;
+    bl_count[0] = 0;
+    uint32_t c = 0;
+    next_code[0] = 0;
+    for (int b = 1; b < 16; ++b) { c = (c + bl_count[b - 1]) << 1; next_code[b] = c; }
+    for (int i = 0; i < n; ++i) {
+        const uint32_t len = lengths[i];
+        uint32_t v = 0;
+        if (len) {
+            const uint32_t nc = next_code[len];
+            next_code[len] = nc + 1;
+            v = (len << 16) | bitrev(nc, len);
+        }
+        codes[i] = v;
+    }
+}
+
+// huffman.cpp:158-216 FromLengths/AddRecords: RLE of one code-length array into (value, payload) records,
+// packed value | payload << 8; meta frequencies accumulate. Returns the new record count.
+__device__ inline int rle_add(uint16_t* recs, int nv, uint32_t* metaF, int value, int count)
+{
+    if (count == 0) return nv;
+    if (value == 0) {
+        while (count >= 3) {
+            int w = count < 138 ? count : 138;
+            count -= w;
+            int sym = w < 11 ? 17 : 18;
+            recs[nv++] = (uint16_t)(sym | (w << 8)); metaF[sym]++;
+        }
+    } else {
+        recs[nv++] = (uint16_t)value; metaF[value]++;
+        count--;
+        while (count >= 3) {
+            int w = count < 6 ? count : 6;
+            count -= w;
+            recs[nv++] = (uint16_t)(16 | (w << 8)); metaF[16]++;
+        }
+    }
+    for (int i = 0; i < count; ++i) { recs[nv++] = (uint16_t)value; metaF[value]++; }
+    return nv;
+}
+__device__ inline int rle_lengths(const uint8_t* lengths, int n, uint16_t* recs, int nv, uint32_t* metaF)
+{
+    int cur = -1, count = 0;
+    for (int i = 0; i < n; ++i) {
+        if (lengths[i] == cur) { count++; continue; }
+        nv = rle_add(recs, nv, metaF, cur, count);
+        cur = lengths[i];
+        count = 1;
+    }
+    return rle_add(recs, nv, metaF, cur, count);
+}
+
+// backward twin of wave_extend_match: number of equal bytes going down from src[a-1] / src[b-1], at most
+// maxlen (> 8; the first 8 are known equal). 4 bytes per lane.
+__device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t a, int64_t b, uint32_t maxlen)
+{
+    const uint32_t o = 8 + 4 * (uint32_t)lane_id();          // bytes a-o-4 .. a-o-1
+    uint32_t d = 0;
+    const bool act = o < maxlen;
+    if (act) {
+        // the caller guarantees b - maxlen >= start of readable memory; a 4-byte load may reach up to 3 bytes
+        // below a-maxlen, which is still readable unless it crosses the buffer start: assemble byte-wise there
+        if (o + 4 <= maxlen) d = load32(src + a - o - 4) ^ load32(src + b - o - 4);
+        else {
+            for (uint32_t i = 0; i < 4; ++i)
+                if (o + i < maxlen) d |= (uint32_t)(src[a - o - 1 - i] ^ src[b - o - 1 - i]) << (8 * (3 - i));
+        }
+    }
+    const uint64_t neq = ballot(act && d != 0);
+    if (!neq) return maxlen;
+    const int k = __builtin_ctzll(neq);
+    const uint32_t dk = readlane(d, k);
+    const uint32_t len = 8 + 4 * (uint32_t)k + ((uint32_t)__builtin_clz(dk) >> 3);   // top byte = nearest
+    return len < maxlen ? len : maxlen;
+}
+
+struct zz_l2_params {
+    zz_packet_params pk;
+    uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
+};
+
+#define ZZ_L2_LDS_BYTES (16384 + 4096 + 4096 + 1040 + 1280 + 128 + 80 + 512 + 1152 + 256)
+
+__global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
+{
+    const zz_packet_params& P = Q.pk;
+    // ---- LDS carve-up --------------------------------------------------------------------------------------
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES];
+    uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table; Huffman scratch afterwards
+    uint64_t* cov = (uint64_t*)(lds + 16384);                     // 4096: position covered by a match
+    uint64_t* mst = (uint64_t*)(lds + 16384 + 4096);              // 4096: position starts a match
+    uint16_t* mcount = (uint16_t*)(lds + 24576);                  // 1040: matches before block b (exclusive scan)
+    uint32_t* symF = (uint32_t*)(lds + 24576 + 1040);             // 1280: 286 lit/len + pad | 30 dist at [288..318)
+    uint32_t* distF = symF + 288;
+    uint32_t* dcodes = (uint32_t*)(lds + 24576 + 1040 + 1280);    // 128: 30 distance codes
+    uint32_t* metaF = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128);   // 80: 19 meta frequencies
+    uint32_t* ring_words = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128 + 80);   // 512
+    uint32_t* codes = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128 + 80 + 512);  // 1152: 286 lit/len codes
+    uint32_t* misc = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128 + 80 + 512 + 1152);   // 256: lane-0 results [0..3], code-generation work area [16..48)
+    // Huffman scratch inside the (dead) hash table
+    huff_scratch S;
+    S.rec_freq = (uint32_t*)(lds);                 // 1152
+    S.rec_id = (uint16_t*)(lds + 1152);            // 576
+    S.t_freq = (uint32_t*)(lds + 1728);            // 2304
+    S.t_left = (uint16_t*)(lds + 4032);            // 1152
+    S.t_right = (uint16_t*)(lds + 5184);           // 1152
+    S.t_bits = (uint8_t*)(lds + 6336);             // 576
+    uint8_t* lens = (uint8_t*)(lds + 6912);        // 320: lit/len lengths, then dist lengths at [288..318)
+    uint8_t* metaLens = (uint8_t*)(lds + 7232);    // 32
+    uint32_t* metaCodes = (uint32_t*)(lds + 7264); // 80
+    uint16_t* rle = (uint16_t*)(lds + 7344);       // up to 316+30 records -> 704 bytes
+
+    const int lane = lane_id();
+    l2_token* tokens = (l2_token*)(Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES);
+
+    for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
+        const uint64_t off = (uint64_t)k * P.packet_size;
+        const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
+        const bool is_final = P.last_is_final && k == P.npk - 1;
+        const uint32_t n = is_final ? len : len - 1;     // bytes of the compressing AddData
+        const uint8_t* src = P.src + off;
+        const uint8_t* end = P.src + P.n;
+        const uint64_t before = P.halo + off;            // input bytes in front of the packet (D4: stop at 0)
+        uint8_t* out = P.slots + (uint64_t)k * P.slot_stride;
+
+        __syncthreads();
+        {
+            uint4* z = (uint4*)lds;
+            for (int i = lane; i < (16384 + 8192) / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T, cov, mst
+            for (int i = lane; i < 320; i += ZZ_WAVE) symF[i] = 0;
+            if (lane < 20) metaF[lane] = 0;
+        }
+        bitring ring;
+        ring_init(ring, ring_words, out);
+
+        if (P.cks_kind == ZZ_CKS_ADLER) {
+            zz_cks c = wave_adler(src, len);
+            if (lane == 0) P.cks[k] = c;
+        }
+
+        if (n > 0) {
+            // ================= token pass (encoder.cpp:217-248, 375-440) ===========================================
+            const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
+            uint32_t ntok = 0;
+            uint32_t B = 1;                 // backRefEnd (:380)
+            uint32_t nextProbe = 1;         // j (:383)
+            uint32_t batchEnd = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
+            uint32_t skipPos = 0;           // position that must not be inserted in the current block (0 = byte 0)
+            for (uint32_t base = 0; base < target; base += 64) {
+                if (base >= batchEnd) {
+                    // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first
+                    // byte is inserted only if the last match covered it
+                    const uint32_t s2 = B > batchEnd ? B : batchEnd;
+                    skipPos = B >= batchEnd ? 0xFFFFFFFFu : batchEnd;
+                    B = s2 + 1;
+                    nextProbe = s2 + 1;
+                    const uint32_t rest = target - s2;
+                    batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
+                }
+                const uint32_t q = base + lane;
+                const bool ins = q < n && q != skipPos && q != 0;
+                const uint32_t w4 = q < n ? load32_safe(src + q, end) : 0;
+                const uint32_t h = calc_hash3(w4);                            // CalcHash(source + j), :388
+                uint32_t old = 0;
+                if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1); }            // :389-390 / :474-480
+                __syncthreads();
+                const bool lost = ins && T[h] != (uint16_t)(q + 1);
+                uint64_t lostmask = ballot(lost);
+                uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
+                while (lostmask) {
+                    const int l0 = __builtin_ctzll(lostmask);
+                    const uint32_t hv = readlane(h, l0);
+                    const bool mine = ins && h == hv;
+                    const uint64_t set = ballot(mine);
+                    const uint64_t below = set & ((1ull << lane) - 1);
+                    if (mine && below) cand1 = base + (63 - __builtin_clzll(below)) + 1;   // nearest earlier member
+                    if (mine && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);          // highest member wins
+                    lostmask &= ~set;
+                }
+                skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
+
+                if (base + 64 > nextProbe && nextProbe < batchEnd) {
+                    // ---- quick compare info for all 64 probes of this block --------------------------------------
+                    const bool has = ins && cand1 != 0 && q < batchEnd;
+                    const uint32_t c = cand1 - 1;
+                    uint32_t fwd8 = 0, bwd8 = 0, room = 0;
+                    if (has) {
+                        const uint64_t x = load64_safe(src + q, end) ^ load64_safe(src + c, end);   // :399
+                        fwd8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
+                        const uint64_t cb = before + c;                        // bytes in front of the candidate
+                        room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
+                        if (room >= 8) {
+                            const uint64_t y = load64(src + (int64_t)q - 8) ^ load64(src + (int64_t)c - 8);
+                            bwd8 = y ? (uint32_t)__builtin_clzll(y) >> 3 : 8;
+                        } else {
+                            while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
+                        }
+                    }
+                    // ---- the greedy walk --------------------------------------------------------------------------
+                    for (;;) {
+                        const uint32_t pend = q - B;                            // j - backRefEnd (:404)
+                        uint32_t bq = bwd8 < room ? bwd8 : room;
+                        bq = bq < pend ? bq : pend;
+                        const bool pred = has && q >= nextProbe && fwd8 + bq >= 4;   // :406-407
+                        const uint64_t m = ballot(pred);
+                        if (!m) break;
+                        const int e = __builtin_ctzll(m);
+                        const uint32_t qe = base + (uint32_t)e;
+                        const uint32_t ce = readlane(c, e);
+                        uint32_t fwd = readlane(fwd8, e);
+                        if (fwd == 8) fwd = wave_extend_match(src, qe, ce, ZZ_MAX_LEN, end);          // remain(), :64-90
+                        uint32_t bw = readlane(bq, e);
+                        const uint32_t blim = readlane(room < pend ? room : pend, e);
+                        if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
+                        uint32_t mlen = fwd + bw;
+                        if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                       // :412-415
+                        const uint32_t ms = qe - bw;                                                    // :416
+                        if (lane == 0) {
+                            l2_token t; t.start = (uint16_t)ms; t.dist = (uint16_t)(qe - ce); t.len = (uint16_t)mlen; t.pad = 0;
+                            tokens[ntok] = t;                                                           // :420
+                        }
+                        ntok++;
+                        // status bitmaps: bits [ms, ms+mlen) covered, bit ms = match start
+                        {
+                            const uint32_t w0 = ms >> 6, w1 = (ms + mlen - 1) >> 6;
+                            const uint32_t wi = w0 + lane;
+                            if (wi <= w1) {
+                                const uint32_t lo = wi == w0 ? (ms & 63) : 0;
+                                const uint32_t hi = wi == w1 ? ((ms + mlen - 1) & 63) : 63;
+                                const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
+                                atomicOr((unsigned long long*)&cov[wi], (unsigned long long)mask);
+                            }
+                            if (lane == 0) atomicOr((unsigned long long*)&mst[w0], 1ull << (ms & 63));
+                        }
+                        B = ms + mlen;                                                                  // :422
+                        nextProbe = B + 1;                                                              // :424
+                        if (nextProbe >= base + 64) break;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ================= histograms (encoder.cpp:442-471) ===============================================
+            const uint32_t nblk = (n + 63) >> 6;
+            {   // exclusive scan of per-block match counts
+                uint32_t carry = 0;
+                for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+                    const uint32_t b = b0 + lane;
+                    const uint32_t cnt = b < nblk ? (uint32_t)__builtin_popcountll(mst[b]) : 0;
+                    const uint32_t incl = wave_scan_incl(cnt);
+                    if (b < nblk) mcount[b] = (uint16_t)(carry + incl - cnt);
+                    carry += readlane(incl, 63);
+                }
+            }
+            __syncthreads();
+            for (uint32_t b = 0; b < nblk; ++b) {
+                const uint64_t cw = cov[b], mw = mst[b];
+                const uint32_t q = (b << 6) + lane;
+                if (q < n) {
+                    if (!((cw >> lane) & 1)) atomicAdd(&symF[src[q]], 1u);
+                    else if ((mw >> lane) & 1) {
+                        const l2_token t = tokens[mcount[b] + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+                        uint32_t sym, eb, ev, bucket;
+                        length_symbol(t.len, sym, eb, ev);
+                        atomicAdd(&symF[sym], 1u);
+                        dist_symbol(t.dist, bucket, eb, ev);
+                        atomicAdd(&distF[bucket], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ================= code construction (lane 0) =====================================================
+            if (lane == 0) {
+                symF[256] += 1;                                                  // :470
+                int64_t bits = 0;
+                calc_lengths(S, symF, 286, 15, lens);                            // ComputeCodes, :171-176
+                int nrec = rle_lengths(lens, 286, rle, 0, metaF);
+                const int nSymRecs = nrec;
+                for (int i = 0; i < 286; ++i) {                                  // CountBits, :178-187
+                    uint32_t eb = i < 265 || i == 285 ? 0 : (uint32_t)(i - 261) >> 2;
+                    bits += (int64_t)symF[i] * (lens[i] + eb);
+                }
+                calc_lengths(S, distF, 30, 15, lens + 288);
+                nrec = rle_lengths(lens + 288, 30, rle, nrec, metaF);
+                for (int i = 0; i < 30; ++i) {
+                    uint32_t eb = i < 4 ? 0 : (uint32_t)(i - 2) >> 1;
+                    bits += (int64_t)distF[i] * (lens[288 + i] + eb);
+                }
+                calc_lengths(S, metaF, 19, 7, metaLens);                         // :263-265
+                int64_t total = 3 + 5 + 5 + 4 + 3 * 19 + bits;                   // :267
+                for (int i = 0; i < nrec; ++i) {                                 // WriteLengths<LengthCounter>, :20-46
+                    const uint32_t v = rle[i] & 0xFF;
+                    total += metaLens[v] + (v == 16 ? 2 : v == 17 ? 3 : v == 18 ? 7 : 0);
+                }
+                misc[0] = (uint32_t)((total + 8) / 8);                           // requiredLength, :271
+                misc[1] = (uint32_t)nSymRecs;
+                misc[2] = (uint32_t)nrec;
+            }
+            __syncthreads();
+            const uint32_t required = misc[0];
+            const uint32_t nrec = misc[2];
+
+            if (required >= n) {
+                // ================= UncompressedFallback (encoder.cpp:305-317, 482-502) ==========================
+                // n <= 32767 < 65535: one stored block. BFINAL as passed by the caller (:274).
+                if (lane == 0) {
+                    out[0] = is_final ? 1 : 0;
+                    out[1] = (uint8_t)n; out[2] = (uint8_t)(n >> 8);
+                    out[3] = (uint8_t)~n; out[4] = (uint8_t)(~n >> 8);
+                }
+                coop_copy(out + 5, src, n, lane, ZZ_WAVE);
+                __syncthreads();
+                uint32_t bytes = 5 + n;
+                if (!is_final) {
+                    if (lane == 0) {
+                        uint8_t* t = out + bytes;
+                        t[0] = 0; t[1] = 1; t[2] = 0; t[3] = 0xFE; t[4] = 0xFF; t[5] = src[len - 1];
+                    }
+                    bytes += 6;
+                }
+                if (lane == 0) P.sizes[k] = bytes;
+                continue;
+            }
+
+            // ================= dynamic block ====================================================================
+            if (lane == 0) {
+                generate_codes(lens, 286, codes, misc + 16);                      // huffman::generate
+                generate_codes(lens + 288, 30, dcodes, misc + 16);
+                generate_codes(metaLens, 19, metaCodes, misc + 16);
+            }
+            __syncthreads();
+            // StartBlock(UserDefinedHuffman, final) + HLIT=29 HDIST=29 HCLEN=15 (:280-285)
+            ring_append_uniform(ring, (is_final ? 1u : 0u) | (2u << 1) | (29u << 3) | (29u << 8) | (15u << 13), 17);
+            {   // 19 x 3 bits in `order` (:287-290)
+                const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+                uint32_t v = 0;
+                for (int i = 0; i < 19; ++i) if (lane == i) v = metaLens[order[i]];
+                ring_append(ring, v, lane < 19 ? 3 : 0);
+            }
+            for (uint32_t r0 = 0; r0 < nrec; r0 += 64) {                          // WriteLengths x2 (:292-293)
+                const uint32_t i = r0 + lane;
+                uint32_t bits = 0, nb = 0;
+                if (i < nrec) {
+                    const uint32_t v = rle[i] & 0xFF, pay = rle[i] >> 8;
+                    const uint32_t mc = metaCodes[v];
+                    nb = mc >> 16; bits = mc & 0xFFFF;
+                    if (v == 16) { bits |= (pay - 3) << nb; nb += 2; }
+                    else if (v == 17) { bits |= (pay - 3) << nb; nb += 3; }
+                    else if (v == 18) { bits |= (pay - 11) << nb; nb += 7; }
+                }
+                ring_append(ring, bits, nb);
+            }
+            // body: WriteRecords (:149-169) by position
+            for (uint32_t b = 0; b < nblk; ++b) {
+                const uint64_t cw = cov[b], mw = mst[b];
+                const uint32_t q = (b << 6) + lane;
+                uint64_t bits = 0; uint32_t nb = 0;
+                const uint64_t live = ~cw | mw;                                    // literal or match start
+                if (q < n && ((live >> lane) & 1)) {
+                    if (!((cw >> lane) & 1)) {
+                        const uint32_t cd = codes[src[q]];
+                        bits = cd & 0xFFFF; nb = cd >> 16;
+                    } else {
+                        const l2_token t = tokens[mcount[b] + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+                        uint32_t sym, eb, ev, bucket, deb, dev;
+                        length_symbol(t.len, sym, eb, ev);
+                        const uint32_t lc = codes[sym];
+                        uint32_t ln = lc >> 16;
+                        uint64_t v = (lc & 0xFFFF) | ((uint64_t)ev << ln);          // Merge, :121-124
+                        ln += eb;
+                        dist_symbol(t.dist, bucket, deb, dev);
+                        const uint32_t dc = dcodes[bucket];
+                        v |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
+                        ln += dc >> 16;
+                        v |= (uint64_t)dev << ln;
+                        ln += deb;
+                        bits = v; nb = ln;
+                    }
+                }
+                if (b + 1 < nblk && (live == 0)) continue;                         // block wholly inside a match
+                ring_append64(ring, bits, nb);
+            }
+            {   // codes[256] (:300)
+                const uint32_t cd = codes[256];
+                ring_append_uniform(ring, cd & 0xFFFF, cd >> 16);
+            }
+        }
+        if (!is_final) {
+            // one stored byte = byte alignment (zzflate.cpp:118-120)
+            ring_append_uniform(ring, 0, 3);
+            ring_pad_to_byte(ring);
+            ring_append_uniform(ring, 0xFFFE0001u, 32);
+            ring_append_uniform(ring, src[len - 1], 8);
+        } else if (n == 0) {
+            ring_append_uniform(ring, 1u | (1u << 1), 3);   // empty input: one empty fixed block (D8 divergence)
+            ring_append_uniform(ring, 0, 7);
+        }
+        const uint32_t bytes = ring_finish(ring);
+        if (lane == 0) {
+            P.sizes[k] = bytes;
+            if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+        }
+    }
+}
+
+static inline uint32_t l2_grid(uint32_t npk)
+{
+    const uint32_t resident = 256 * 5;      // CUs x workgroups the LDS budget admits
+    return npk < resident ? npk : resident;
+}
+static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, hipStream_t st)
+{
+    zz_l2_params q; q.pk = pp; q.scratch = scratch;
+    hipLaunchKernelGGL(k_encode_l2, dim3(l2_grid(pp.npk)), dim3(ZZ_WAVE), 0, st, q);
+}
+
+}  // namespace zz
