@@ -1,0 +1,34 @@
+"""Diagnostic: per-phase cycle shares of k_encode_l1 from a -DZZ_PROF build (s_memtime stamps).
+Builds a separate library (never the shipped one), runs one encode of synthetic text, prints shares."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+lib = os.path.join(ROOT, "gpurun_out", "libzz_prof.so")
+os.makedirs(os.path.dirname(lib), exist_ok=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZZ_PROF", "-o", lib,
+                os.path.join(ROOT, "zzflate_amd/csrc/zz_api.hip"), os.path.join(ROOT, "zzflate_amd/csrc/zz_cxx_shim.cpp")], check=True)
+L = ctypes.CDLL(lib)
+u64, vp, ci, u32 = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
+h = vp()
+assert L.zz_ctx_create(0, ctypes.byref(h)) == 0
+L.zz_bound.restype = u64
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+n = mib << 20
+src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+L.zz_generate_device(h, ci(kind), u64(0x5EED0002), u64(0), vp(src.data_ptr()), u64(n), vp(0))
+cap = L.zz_bound(u64(n), ci(0), ci(1), u32(32768))
+dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+out = u64(0)
+for it in range(2):
+    rc = L.zz_encode_device(h, vp(src.data_ptr()), u64(n), vp(dst.data_ptr()), u64(cap), ctypes.byref(out), ci(0), ci(1), u32(32768), vp(0))
+    assert rc == 0
+    prof = (ctypes.c_ulonglong * 16)()
+    L.zz_debug_read_prof(h, prof)
+names = ["adler+init", "hash", "probe+dups", "len/info VALU", "walk", "repair", "codes", "ring_append", "tail", "wait cand+w loads"]
+tot = sum(prof[:10])
+print(f"input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; groups {prof[10]}, events {prof[11]}, extensions {prof[12]}")
+print(f"bytes/group {n / max(1, prof[10]):.1f}, events/group {prof[11] / max(1, prof[10]):.2f}, cycles/group {tot / max(1, prof[10]):.0f}")
+for i, nm in enumerate(names):
+    print(f"  {nm:16s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):8.0f} cyc/group")

@@ -47,6 +47,7 @@ struct zz_ctx {
     uint8_t* l2_scratch = nullptr; uint64_t l2_scratch_cap = 0;
     zz_result* d_res = nullptr; zz_cks_total* d_cks_total = nullptr; uint32_t* d_err = nullptr;
     zz_result* h_res = nullptr;          // pinned
+    unsigned long long* d_prof = nullptr; // 16 counters for diagnostic (-DZZ_PROF) builds
     // staging for the host-buffer entry points
     uint8_t* stage_in = nullptr;  uint64_t stage_in_cap = 0;
     uint8_t* stage_out = nullptr; uint64_t stage_out_cap = 0;
@@ -97,6 +98,8 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
     HIPCHK(hipMalloc(&c->d_res, sizeof(zz_result)));
     HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
     HIPCHK(hipMalloc(&c->d_err, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -110,7 +113,7 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
     (void)hipFree(c->l2_scratch);
-    (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err);
+    (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
     (void)hipFree(c->stage_in); (void)hipFree(c->stage_out);
     (void)hipHostFree(c->h_res);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -122,6 +125,14 @@ extern "C" uint64_t zz_ctx_workspace_bytes(const zz_ctx* c)
 {
     if (!c) return 0;
     return c->slots_cap + c->npk_cap * (4 + 8 + sizeof(zz_cks)) + c->l2_scratch_cap + c->stage_in_cap + c->stage_out_cap;
+}
+// diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
+extern "C" int zz_debug_read_prof(zz_ctx* c, unsigned long long out[16])
+{
+    if (!c) return ZZ_E_ARG;
+    HIPCHK(hipMemcpy(out, c->d_prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
+    return ZZ_OK;
 }
 extern "C" void zz_ctx_enable_timing(zz_ctx* c, int on) { if (c) { c->timing = on != 0; c->have_time = false; } }
 extern "C" double zz_ctx_last_kernel_ms(zz_ctx* c)
@@ -200,7 +211,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         zz_packet_params pp;
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
         pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind;
-        pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err;
+        pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof;
 
         if (cks_kind == ZZ_CKS_CRC) {
             uint32_t g = npk < 65536 ? npk : 65536;

@@ -34,4 +34,23 @@ struct zz_packet_params {
     uint32_t* sizes;          // out: bytes written per packet
     zz_cks* cks;              // out: checksum partial per packet (may be null when cks_kind == NONE)
     uint32_t* err;            // out: sticky error word (slot overflow etc.)
+    unsigned long long* prof; // diagnostic builds (-DZZ_PROF) only: per-phase cycle sums; ignored otherwise
 };
+
+#ifdef ZZ_PROF
+#define ZZ_PROF_DECL unsigned long long prof_acc[16] = {0}; unsigned long long prof_last; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last) :: "memory");
+// stamp form of cdna_hip_programming.md section 7: one asm statement, fenced against the scheduler
+#define ZZ_T(i) do { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    prof_acc[i] += _t - prof_last; prof_last = _t; } while (0)
+// diagnostic only: drain outstanding vector-memory operations so that the next stamp prices their latency
+#define ZZ_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define ZZ_C(i, v) do { prof_acc[i] += (v); } while (0)
+#define ZZ_PROF_FLUSH(P) do { if (threadIdx.x == 0 && (P).prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&(P).prof[_i], prof_acc[_i]); } while (0)
+#else
+#define ZZ_PROF_DECL
+#define ZZ_T(i)
+#define ZZ_DRAIN()
+#define ZZ_C(i, v)
+#define ZZ_PROF_FLUSH(P)
+#endif

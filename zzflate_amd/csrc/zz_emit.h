@@ -26,13 +26,13 @@ __device__ __forceinline__ void ring_init(bitring& r, uint32_t* lds_ring, uint8_
     r.bitpos = 0;
     r.flushed = 0;
     for (int i = lane_id(); i < ZZ_RING_WORDS; i += ZZ_WAVE) lds_ring[i] = 0;
-    __syncthreads();
+    ZZ_WAVE_SYNC();
 }
 
 // store the words completed so far; caller guarantees at most 64 are pending
 __device__ __forceinline__ void ring_flush_full(bitring& r)
 {
-    __syncthreads();
+    ZZ_WAVE_SYNC();
     const uint32_t full = r.bitpos >> 5;
     const uint32_t w = r.flushed + lane_id();
     if (w < full) {
@@ -41,7 +41,7 @@ __device__ __forceinline__ void ring_flush_full(bitring& r)
         r.out32[w] = v;
     }
     r.flushed = full;
-    __syncthreads();
+    ZZ_WAVE_SYNC();
 }
 
 // every lane appends `nb` bits (0 = nothing; nb <= 32, value already masked) in lane order
@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t ring_finish(bitring& r)
     ring_pad_to_byte(r);
     const uint32_t bytes = r.bitpos >> 3;
     const uint32_t words = (bytes + 3) >> 2;
-    __syncthreads();
+    ZZ_WAVE_SYNC();
     const uint32_t w = r.flushed + lane_id();
     if (w < words) r.out32[w] = r.ring[w & (ZZ_RING_WORDS - 1)];
     return bytes;

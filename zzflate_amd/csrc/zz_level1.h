@@ -17,22 +17,41 @@
 //      are extended by all 64 lanes at once (4 bytes per lane);
 //   4. the table is repaired: lanes the parse skipped restore the old entry, and among committed lanes
 //      sharing a hash the highest position wins -- exactly the state the serial loop leaves;
-//   5. tokens are turned into fixed-Huffman fragments and appended through the bit ring (zz_emit.h).
+//   5. tokens are turned into fixed-Huffman fragments and appended through the bit ring (zz_emit.h) -- one
+//      iteration later, in the shadow of the next group's candidate loads (software pipelining).
+//
+// Measured on MI355X (rocprofv3 SQ counters, profiles/): a wave retires about one instruction per 4 cycles and
+// only ~9 waves fit a CU (the 16 KiB table), so the loop is bound by its dynamic instruction count and by
+// dependent LDS/memory round trips, not by bandwidth. Hence: no s_barrier (one wave per workgroup, LDS ops
+// execute in order), candidate loads issued before the dup scan, a branch-light fast path in the walk, and
+// bounds-checked loads only in the last two packets of a shard.
 #pragma once
 #include "zz_checksum.h"
 #include "zz_emit.h"
 
 namespace zz {
 
+template <bool SAFE> __device__ __forceinline__ uint64_t ld64(const uint8_t* p, const uint8_t* end)
+{
+    if (SAFE) return load64_safe(p, end);
+    return load64(p);
+}
+template <bool SAFE> __device__ __forceinline__ uint32_t ld32(const uint8_t* p, const uint8_t* end)
+{
+    if (SAFE) return load32_safe(p, end);
+    return load32(p);
+}
+
 // compare src[pe+8 ..) with src[cand+8 ..) with the whole wave, 4 bytes per lane; returns the match
 // length (>= 8) clamped to maxlen. Only called when the first 8 bytes are known equal.
+template <bool SAFE>
 __device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32_t pe, uint32_t cand,
                                                       uint32_t maxlen, const uint8_t* end)
 {
     const uint32_t o = 8 + 4 * (uint32_t)lane_id();
     uint32_t d = 0;
     const bool act = o < maxlen;
-    if (act) d = load32_safe(src + pe + o, end) ^ load32_safe(src + cand + o, end);
+    if (act) d = ld32<SAFE>(src + pe + o, end) ^ ld32<SAFE>(src + cand + o, end);
     const uint64_t neq = ballot(act && d != 0);
     if (!neq) return maxlen;
     const int k = __builtin_ctzll(neq);
@@ -44,6 +63,209 @@ __device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32
 __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encoder.cpp:11-17
 {
     return ((three_bytes & 0xFFFFFFu) * 0x00d68664u) >> (32 - ZZ_HASH_BITS);
+}
+
+// per-lane walk info, packed into one VGPR so that the scalar walk needs a single v_readlane per event
+#define ZZ_WI_LENA(i) ((i) & 15u)            // match length vs the table candidate, 8 = "8 or more"
+#define ZZ_WI_LENB(i) (((i) >> 4) & 15u)     // match length vs the nearest earlier same-hash lane
+#define ZZ_WI_QLANE(i) (((i) >> 8) & 63u)    // that lane
+#define ZZ_WI_DUP 0x4000u                    // lane has an earlier same-hash lane in the group
+#define ZZ_WI_HARD 0x8000u                   // its hash occurs more than twice: resolve generically
+#define ZZ_WI_EXTA 0x10000u                  // lenA is "8 or more" and more bytes remain: extend
+#define ZZ_WI_EXTB 0x20000u
+
+// a committed token as it waits one iteration for emission: bit31 match (len<<16 | dist), bit30 literal (byte)
+#define ZZ_TOK_MATCH 0x80000000u
+#define ZZ_TOK_LIT 0x40000000u
+
+__device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lcodes, uint32_t tok)
+{
+    uint32_t bits = 0, nb = 0;
+    if (tok & ZZ_TOK_MATCH) {
+        const uint32_t tlen = (tok >> 16) & 0x1FF, tdist = tok & 0xFFFF;
+        const uint32_t lc = lcodes[tlen];                                // lcodes_f[matchLength], encoder.cpp:358
+        const uint32_t ll = lc >> 16;
+        uint32_t bucket, eb, ev;
+        dist_symbol(tdist, bucket, eb, ev);                              // WriteDistance, encoder.cpp:135-141
+        bits = (lc & 0xFFFF) | (bitrev(bucket, 5) << ll) | (ev << (ll + 5));
+        nb = ll + 5 + eb;
+    } else if (tok & ZZ_TOK_LIT) {
+        fixed_code(tok & 0xFF, bits, nb);                                // codes_f[*sourcePtr], encoder.cpp:367
+    }
+    ring_append(ring, bits, nb);
+}
+
+template <bool SAFE>
+__device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16_t* T, const uint32_t* lcodes,
+                                               bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n)
+{
+    const int lane = lane_id();
+    uint32_t cur = 0;
+    uint32_t ptok = 0;                                                    // previous group's tokens
+    uint64_t w = (uint32_t)lane < n ? ld64<SAFE>(src + lane, end) : 0;    // 8 bytes at this lane's position
+    while (cur < n) {
+        const uint32_t nact = (n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE;
+        const uint64_t actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1);
+        const uint32_t p = cur + lane;
+        const bool active = lane < (int)nact;
+
+        // (1) hash, probe + speculative insert; the candidate's bytes are requested at once
+        const uint32_t h = calc_hash3((uint32_t)(w >> 8));              // bytes p+1..p+3 (encoder.cpp:344)
+        uint32_t old = 0;
+        if (active) {
+            old = T[h];                                                 // encoder.cpp:345
+            T[h] = (uint16_t)(p + 1);                                   // encoder.cpp:346
+        }
+        uint64_t wc = 0;
+        if (active && old) wc = ld64<SAFE>(src + (old - 1), end);       // encoder.cpp:350
+        ZZ_WAVE_SYNC();
+        uint32_t rb = 0;
+        if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
+
+        // (1a) the previous group's tokens leave while those loads are in flight
+        if (cur) l1_emit_tokens(ring, lcodes, ptok);
+
+        // (1b) which lanes share a hash inside the group?
+        uint64_t lostmask = ballot(active && rb != ((p + 1) & 0xFFFF));
+        uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
+        uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
+        uint32_t info = 0;
+        while (lostmask) {
+            const int l0 = __builtin_ctzll(lostmask);
+            const uint32_t hv = readlane(h, l0);
+            const bool mine = active && h == hv;
+            const uint64_t set = ballot(mine);
+            if (mine) {
+                myset = set;
+                const uint64_t below = set & ((1ull << lane) - 1);
+                if (below) {
+                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 8);
+                    if (__builtin_popcountll(set) > 2) info |= ZZ_WI_HARD;
+                }
+            }
+            multimask |= set;
+            lostmask &= ~set;
+        }
+
+        // (2) lengths against both possible candidates, capped at 8 ("8 or more")
+        const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
+        const uint32_t cap8 = left < 8 ? left : 8;
+        uint64_t x = ~0ull;
+        uint32_t la = 0;
+        if (active && old) {
+            x = w ^ wc;
+            la = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
+            if (la > cap8) la = cap8;
+        }
+        info |= la;
+        if (la == 8 && left > 8) info |= ZZ_WI_EXTA;
+        if (multimask) {
+            // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
+            const int ql = (info & ZZ_WI_DUP) ? (int)ZZ_WI_QLANE(info) : lane;
+            const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), ql) << 32) | (uint32_t)__shfl((int)w, ql);
+            if (info & ZZ_WI_DUP) {
+                const uint64_t xq = w ^ wq;
+                uint32_t lb = xq ? (uint32_t)__builtin_ctzll(xq) >> 3 : 8;
+                if (lb > cap8) lb = cap8;
+                info |= lb << 4;
+                if (lb == 8 && left > 8) info |= ZZ_WI_EXTB;
+            }
+        }
+        // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
+        const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
+        const uint64_t Ms = ballot(active && la >= 4 && !(info & (ZZ_WI_DUP | ZZ_WI_EXTA)));
+
+        // (3) the walk: replays the reference's decisions in order (encoder.cpp:341-368)
+        uint64_t lits = 0, mst = 0, usedB = 0;   // committed literal lanes / match-start lanes / matched the in-group candidate
+        uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events
+        uint32_t pos = 0;
+        for (;;) {
+            const uint64_t Er = E & (~0ull << pos);
+            if (!Er) { lits |= actmask & (~0ull << pos); pos = nact; break; }
+            const int e = __builtin_ctzll(Er);
+            lits |= ((1ull << e) - 1) & (~0ull << pos);                  // literals pos..e-1 (encoder.cpp:367)
+            if ((Ms >> e) & 1) {
+                mst |= 1ull << e;                                        // encoder.cpp:356
+                pos = (uint32_t)e + readlane(la, e);                     // encoder.cpp:361-362
+            } else {
+                const uint32_t inf = readlane(info, e);
+                const uint32_t pe = cur + (uint32_t)e;
+                const uint32_t maxlen = (n - pe) < ZZ_MAX_LEN ? (n - pe) : ZZ_MAX_LEN;
+                uint32_t mlen;
+                if (!(inf & ZZ_WI_HARD)) {
+                    const bool useB = (inf & ZZ_WI_DUP) && (((lits | mst) >> ZZ_WI_QLANE(inf)) & 1);
+                    mlen = useB ? ZZ_WI_LENB(inf) : ZZ_WI_LENA(inf);
+                    if (mlen >= 4) {
+                        if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
+                            const uint32_t cand = useB ? cur + ZZ_WI_QLANE(inf) : readlane(old, e) - 1;
+                            mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end);
+                            if (lane == e) ovlen = mlen;
+                        }
+                        if (useB) usedB |= 1ull << e;
+                    }
+                } else {
+                    // hash shared by 3+ lanes: candidate = most recent committed lane with my hash, else the table's
+                    const uint64_t S = readlane64(myset, e) & (lits | mst) & ((1ull << e) - 1);
+                    uint32_t cand1 = 0;
+                    uint64_t xe = ~0ull;
+                    if (S) {
+                        const int c = 63 - __builtin_clzll(S);
+                        cand1 = cur + (uint32_t)c + 1;
+                        xe = readlane64(w, e) ^ readlane64(w, c);
+                    } else {
+                        cand1 = readlane(old, e);
+                        if (cand1) xe = readlane64(x, e);
+                    }
+                    mlen = 0;
+                    if ((uint32_t)xe == 0 && maxlen >= 4) {
+                        if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
+                        else mlen = wave_extend_match<SAFE>(src, pe, cand1 - 1, maxlen, end);
+                        if (mlen > maxlen) mlen = maxlen;
+                    }
+                    if (lane == e) { ovlen = mlen; ovcand1 = cand1; }
+                }
+                if (mlen > 3) {
+                    mst |= 1ull << e;
+                    pos = (uint32_t)e + mlen;
+                } else {
+                    lits |= 1ull << e;
+                    pos = (uint32_t)e + 1;
+                }
+            }
+            if (pos >= nact) break;
+        }
+        const uint64_t committed = lits | mst;
+        const uint32_t next = cur + pos;
+        // next group's bytes: in flight while this group is repaired
+        const uint64_t wnext = next + (uint32_t)lane < n ? ld64<SAFE>(src + next + lane, end) : 0;
+
+        // (4) table repair: skipped lanes restore the old entry; among committed lanes sharing a hash the
+        // highest position wins -- the state the serial loop leaves behind
+        const bool is_committed = (committed >> lane) & 1;
+        ZZ_WAVE_SYNC();
+        if (active && !is_committed) T[h] = (uint16_t)old;
+        if (multimask) {
+            ZZ_WAVE_SYNC();
+            const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
+            if (winner) T[h] = (uint16_t)(p + 1);
+        }
+        ZZ_WAVE_SYNC();
+
+        // (5) this group's tokens, emitted by the next iteration
+        ptok = 0;
+        if (is_committed) {
+            if (!((mst >> lane) & 1)) ptok = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
+            else {
+                const bool b = (usedB >> lane) & 1;
+                const uint32_t tlen = ovlen ? ovlen : (b ? ZZ_WI_LENB(info) : ZZ_WI_LENA(info));
+                const uint32_t cand1 = (info & ZZ_WI_HARD) ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 : old);
+                ptok = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 - cand1);
+            }
+        }
+        cur = next;
+        w = wnext;
+    }
+    l1_emit_tokens(ring, lcodes, ptok);
 }
 
 __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
@@ -69,7 +291,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
         for (int l = lane; l <= ZZ_MAX_LEN; l += ZZ_WAVE) lcodes[l] = l >= 3 ? fixed_lcode_packed(l) : 0;
     }
     bitring ring;
-    ring_init(ring, ring_words, out);   // includes the barrier that publishes T and lcodes
+    ring_init(ring, ring_words, out);   // includes the fence that publishes T and lcodes
 
     if (P.cks_kind == ZZ_CKS_ADLER) {
         zz_cks c = wave_adler(src, len);
@@ -79,117 +301,9 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
     if (n > 0) {
         // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
         ring_append_uniform(ring, (is_final ? 1u : 0u) | (1u << 1), 3);
-
-        uint32_t cur = 0;
-        while (cur < n) {
-            const uint32_t nact = (n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE;
-            const uint64_t actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1);
-            const uint32_t p = cur + lane;
-            const bool active = lane < (int)nact;
-
-            // (1) load, hash, probe + speculative insert
-            const uint64_t w = active ? load64_safe(src + p, end) : 0;
-            const uint32_t h = calc_hash3((uint32_t)(w >> 8));          // bytes p+1..p+3 (encoder.cpp:344)
-            uint32_t old = 0;
-            if (active) {
-                old = T[h];                                             // encoder.cpp:345
-                T[h] = (uint16_t)(p + 1);                               // encoder.cpp:346
-            }
-            __syncthreads();
-            const bool lost = active && T[h] != (uint16_t)(p + 1);
-            uint64_t lostmask = ballot(lost);
-            uint64_t dupmask = 0;      // lanes with an earlier same-hash lane in this group
-            uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
-            uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
-            while (lostmask) {
-                const int l0 = __builtin_ctzll(lostmask);
-                const uint32_t hv = readlane(h, l0);
-                const uint64_t set = ballot(active && h == hv);
-                if (active && h == hv) myset = set;
-                dupmask |= set & (set - 1);        // all but the lowest lane of the set
-                multimask |= set;
-                lostmask &= ~set;
-            }
-
-            // (2) compare with the pre-group candidate
-            uint64_t x = ~0ull;
-            if (active && old) x = w ^ load64_safe(src + (old - 1), end);   // encoder.cpp:350
-            // a match needs 4 equal bytes AND 4 bytes left in the block (D1 clamp)
-            const bool m4 = active && old && (uint32_t)x == 0 && p + 4 <= n;
-            const uint64_t M = ballot(m4) & ~dupmask;
-            uint64_t E = (M | dupmask) & actmask;
-
-            // (3) the walk
-            uint64_t committed = 0;     // probed lanes (literals and match starts)
-            uint32_t tlen = 0, tdist = 0;
-            uint32_t pos = 0;
-            for (;;) {
-                const uint64_t Er = E & ~((1ull << pos) - 1);
-                if (!Er) { committed |= actmask & ~((1ull << pos) - 1); pos = nact; break; }
-                const int e = __builtin_ctzll(Er);
-                committed |= ((1ull << e) - 1) & ~((1ull << pos) - 1);   // literals pos..e-1 (encoder.cpp:367)
-                committed |= 1ull << e;
-                const uint32_t pe = cur + (uint32_t)e;
-                uint32_t cand = 0;
-                uint64_t xe = ~0ull;
-                if ((M >> e) & 1) {
-                    cand = readlane(old, e) - 1;
-                    xe = readlane64(x, e);
-                } else {
-                    // dup lane: candidate = most recent committed lane with my hash, else the table's
-                    const uint64_t S = readlane64(myset, e) & committed & ((1ull << e) - 1);
-                    if (S) {
-                        const int c = 63 - __builtin_clzll(S);
-                        cand = cur + (uint32_t)c;
-                        xe = readlane64(w, e) ^ readlane64(w, c);
-                    } else {
-                        const uint32_t o = readlane(old, e);
-                        if (o) { cand = o - 1; xe = readlane64(x, e); }
-                    }
-                }
-                uint32_t mlen = 0;
-                const uint32_t maxlen = (n - pe) < ZZ_MAX_LEN ? (n - pe) : ZZ_MAX_LEN;
-                if ((uint32_t)xe == 0 && maxlen >= 4) {
-                    if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;          // ZeroCount, gcc.h:10-13
-                    else mlen = wave_extend_match(src, pe, cand, maxlen, end);       // remain(), encoder.cpp:64-90
-                    if (mlen > maxlen) mlen = maxlen;
-                }
-                if (mlen > 3) {                                                      // encoder.cpp:356
-                    if (lane == e) { tlen = mlen; tdist = pe - cand; }
-                    pos = (uint32_t)e + mlen;                                        // encoder.cpp:361-362
-                } else {
-                    pos = (uint32_t)e + 1;
-                    E &= ~(1ull << e);
-                }
-                if (pos >= nact) break;
-            }
-
-            // (4) table repair
-            const bool is_committed = (committed >> lane) & 1;
-            if (active && !is_committed) T[h] = (uint16_t)old;
-            if (multimask) {
-                __syncthreads();
-                const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
-                if (winner) T[h] = (uint16_t)(p + 1);
-            }
-
-            // (5) fixed-Huffman fragments
-            uint32_t bits = 0, nb = 0;
-            if (is_committed) {
-                if (tlen == 0) {
-                    fixed_code((uint32_t)(w & 0xFF), bits, nb);                      // codes_f[*sourcePtr]
-                } else {
-                    const uint32_t lc = lcodes[tlen];                                // lcodes_f[matchLength]
-                    const uint32_t ll = lc >> 16;
-                    uint32_t bucket, eb, ev;
-                    dist_symbol(tdist, bucket, eb, ev);                              // WriteDistance, encoder.cpp:135-141
-                    bits = (lc & 0xFFFF) | (bitrev(bucket, 5) << ll) | (ev << (ll + 5));
-                    nb = ll + 5 + eb;
-                }
-            }
-            ring_append(ring, bits, nb);   // barriers inside also order (4) before the next group's probe
-            cur += pos;
-        }
+        // loads may run up to 8 bytes past the packet: only the last two packets can leave the buffer that way
+        if (k + 2 >= P.npk) l1_encode_body<true>(P, T, lcodes, ring, src, end, n);
+        else l1_encode_body<false>(P, T, lcodes, ring, src, end, n);
         // EOB: codes_f[256] = 7 zero bits (encoder.cpp:371)
         ring_append_uniform(ring, 0, 7);
     }

@@ -41,7 +41,7 @@ __device__ __forceinline__ void ring_flush_all_full(bitring& r)
     while ((r.bitpos >> 5) > r.flushed) {
         const uint32_t full = r.bitpos >> 5;
         const uint32_t upto = full - r.flushed > 64 ? r.flushed + 64 : full;
-        __syncthreads();
+        ZZ_WAVE_SYNC();
         const uint32_t w = r.flushed + lane_id();
         if (w < upto) {
             uint32_t v = r.ring[w & (ZZ_RING_WORDS - 1)];
@@ -49,7 +49,7 @@ __device__ __forceinline__ void ring_flush_all_full(bitring& r)
             r.out32[w] = v;
         }
         r.flushed = upto;
-        __syncthreads();
+        ZZ_WAVE_SYNC();
     }
 }
 // every lane appends nb <= 48 bits (so one append adds at most 96 words; the ring holds 128)
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
                         const uint32_t qe = base + (uint32_t)e;
                         const uint32_t ce = readlane(c, e);
                         uint32_t fwd = readlane(fwd8, e);
-                        if (fwd == 8) fwd = wave_extend_match(src, qe, ce, ZZ_MAX_LEN, end);          // remain(), :64-90
+                        if (fwd == 8) fwd = wave_extend_match<true>(src, qe, ce, ZZ_MAX_LEN, end);          // remain(), :64-90
                         uint32_t bw = readlane(bq, e);
                         const uint32_t blim = readlane(room < pend ? room : pend, e);
                         if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102

@@ -5,6 +5,16 @@
 
 namespace zz {
 
+// The encode kernels run ONE wavefront per workgroup. LDS instructions of one wave execute in issue order,
+// so cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt -- only the compiler must keep the
+// program order of the LDS accesses. A wavefront-scope fence does exactly that and emits no instruction
+// (in particular it does not drain outstanding global loads the way __syncthreads() does).
+#define ZZ_WAVE_SYNC()                                              \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+    } while (0)
+
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
