@@ -129,13 +129,15 @@ def main():
     n = args.mib << 20                 # bytes per rank (weak scaling)
     total_n = n * world
     P = args.packet
-    src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
-    ctx.generate(GEN[args.gen], SEEDS[args.gen], rank * n, src, n)     # rank r holds bytes [r*n, (r+1)*n)
+    # rank r holds bytes [r*n, (r+1)*n) of the job's input, plus (for r > 0) the 64 KiB in front of them:
+    # level >= 2 backward match extension may read up to 258 bytes before the shard (zz_encode_shard_device halo)
+    halo = 65536 if rank > 0 else 0
+    buf = torch.empty(halo + n + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate(GEN[args.gen], SEEDS[args.gen], rank * n - halo, buf, halo + n)
+    src = buf[halo:]
     cap = zz.bound(n, 2, args.level, P)
     shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
     gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
-    meta = torch.zeros(2, dtype=torch.int64, device="cuda")
-    metas = torch.zeros(2 * world, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
 
     kernel_ms = []
@@ -147,36 +149,13 @@ def main():
             state["out_bytes"] = w
             state["comp_bytes"] = w
         else:
-            w, cks = ctx.encode_shard(src, n, shard, cap, halo=0, is_last=(rank == world - 1), checksum=fmt,
+            from zzflate_amd import sharded
+            w, cks = ctx.encode_shard(src, n, shard, cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
                                       level=args.level, packet_size=P)
-            meta[0], meta[1] = w, cks
-            dist.all_gather_into_tensor(metas, meta)
-            m = metas.cpu().tolist()
-            sizes, ckss = m[0::2], m[1::2]
-            # one grouped send/recv: every rank's compressed shard lands at its final offset on rank 0
-            hl = len(zz.header(fmt))
-            ops, off = [], hl
-            for r in range(world):
-                if rank == 0 and r != 0:
-                    ops.append(dist.P2POp(dist.irecv, gathered[off:off + sizes[r]], r))
-                elif rank == r and r != 0:
-                    ops.append(dist.P2POp(dist.isend, shard[:sizes[r]], 0))
-                off += sizes[r]
+            # sizes/checksums all-gather + ONE grouped send/recv gather of the compressed shards to rank 0
+            tot = sharded.gather_stream(dist, fmt, shard, w, cks, n, gathered)
             if rank == 0:
-                gathered[hl:hl + sizes[0]].copy_(shard[:sizes[0]])
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-            if rank == 0:
-                tot = 1 if fmt == 0 else 0
-                for r in range(world):
-                    tot = zz.combine(tot, ckss[r], n) if fmt == 0 else (zz.crc32_combine(tot, ckss[r], n) if fmt == 1 else 0)
-                head, tail = zz.header(fmt), zz.trailer(fmt, tot, total_n)
-                if head:
-                    gathered[:hl].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
-                if tail:
-                    gathered[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
-                state["out_bytes"] = off + len(tail)
+                state["out_bytes"] = tot
             state["comp_bytes"] = w
         kernel_ms.append(ctx.last_kernel_ms())
 

@@ -15,17 +15,25 @@ assert L.zz_ctx_create(0, ctypes.byref(h)) == 0
 L.zz_bound.restype = u64
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = mib << 20
 src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 L.zz_generate_device(h, ci(kind), u64(0x5EED0002), u64(0), vp(src.data_ptr()), u64(n), vp(0))
-cap = L.zz_bound(u64(n), ci(0), ci(1), u32(32768))
+cap = L.zz_bound(u64(n), ci(0), ci(level), u32(32768))
 dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 out = u64(0)
 for it in range(2):
-    rc = L.zz_encode_device(h, vp(src.data_ptr()), u64(n), vp(dst.data_ptr()), u64(cap), ctypes.byref(out), ci(0), ci(1), u32(32768), vp(0))
+    rc = L.zz_encode_device(h, vp(src.data_ptr()), u64(n), vp(dst.data_ptr()), u64(cap), ctypes.byref(out), ci(0), ci(level), u32(32768), vp(0))
     assert rc == 0
     prof = (ctypes.c_ulonglong * 16)()
     L.zz_debug_read_prof(h, prof)
+if level >= 2:
+    names = ["init+adler", "token pass", "histograms", "huffman (lane 0)", "codes (lane 0)", "emit"]
+    tot = sum(prof[:6])
+    print(f"level {level} input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; packets {prof[10]}, tokens/packet {prof[11] / max(1, prof[10]):.0f}, cycles/packet {tot / max(1, prof[10]):.0f} = {tot / max(1, prof[10]) / 32768:.1f} cyc/byte")
+    for i, nm in enumerate(names):
+        print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
+    sys.exit(0)
 names = ["adler+init", "hash", "probe+dups", "len/info VALU", "walk", "repair", "codes", "ring_append", "tail", "wait cand+w loads"]
 tot = sum(prof[:10])
 print(f"input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; groups {prof[10]}, events {prof[11]}, extensions {prof[12]}")

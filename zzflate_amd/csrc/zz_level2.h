@@ -267,6 +267,128 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
     return len < maxlen ? len : maxlen;
 }
 
+// ---- token pass ------------------------------------------------------------------------------------------------
+// FirstPass + AddHashEntries over the whole packet (encoder.cpp:217-248, 375-440, 474-480). Returns the number
+// of tokens written to `tokens` (ascending start); sets the covered / match-start bitmaps.
+template <bool SAFE>
+__device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, uint64_t* mst, l2_token* tokens,
+                                                  const uint8_t* src, const uint8_t* end, uint32_t n, uint64_t before)
+{
+    const int lane = lane_id();
+    const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
+    uint32_t ntok = 0;
+    uint32_t B = 1;                 // backRefEnd (:380)
+    uint32_t nextProbe = 1;         // j (:383)
+    uint32_t batchEnd = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
+    uint32_t skipPos = 0;           // position that must not be inserted in the current block (0 = byte 0)
+    uint32_t w4 = (uint32_t)lane < n ? ld32<SAFE>(src + lane, end) : 0;
+    for (uint32_t base = 0; base < target; base += 64) {
+        if (base >= batchEnd) {
+            // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first
+            // byte is inserted only if the last match covered it
+            const uint32_t s2 = B > batchEnd ? B : batchEnd;
+            skipPos = B >= batchEnd ? 0xFFFFFFFFu : batchEnd;
+            B = s2 + 1;
+            nextProbe = s2 + 1;
+            const uint32_t rest = target - s2;
+            batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
+        }
+        const uint32_t q = base + lane;
+        const bool ins = q < n && q != skipPos && q != 0;
+        const uint32_t h = calc_hash3(w4);                            // CalcHash(source + j), :388
+        uint32_t old = 0;
+        if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1); }            // :389-390 / :474-480
+        // next block's hash bytes: in flight during the rest of this block
+        const uint32_t w4next = q + 64 < n ? ld32<SAFE>(src + q + 64, end) : 0;
+        ZZ_WAVE_SYNC();
+        uint32_t rb = 0;
+        if (ins) rb = T[h];
+        uint64_t lostmask = ballot(ins && rb != ((q + 1) & 0xFFFF));
+        uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
+        while (lostmask) {
+            const int l0 = __builtin_ctzll(lostmask);
+            const uint32_t hv = readlane(h, l0);
+            const bool mine = ins && h == hv;
+            const uint64_t set = ballot(mine);
+            const uint64_t below = set & ((1ull << lane) - 1);
+            if (mine && below) cand1 = base + (63 - __builtin_clzll(below)) + 1;   // nearest earlier member
+            ZZ_WAVE_SYNC();
+            if (mine && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);          // highest member wins
+            lostmask &= ~set;
+        }
+        ZZ_WAVE_SYNC();
+        skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
+
+        if (base + 64 > nextProbe && nextProbe < batchEnd) {
+            // ---- quick compare info for all 64 probes of this block --------------------------------------
+            const bool has = ins && cand1 != 0 && q < batchEnd;
+            const uint32_t c = cand1 - 1;
+            uint32_t fwd8 = 0, bwd8 = 0, room = 0;
+            if (has) {
+                const uint64_t x = ld64<SAFE>(src + q, end) ^ ld64<SAFE>(src + c, end);   // :399
+                const uint64_t cb = before + c;                        // bytes in front of the candidate
+                room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
+                if (room >= 8) {
+                    const uint64_t y = load64(src + (int64_t)q - 8) ^ load64(src + (int64_t)c - 8);
+                    bwd8 = y ? (uint32_t)__builtin_clzll(y) >> 3 : 8;
+                } else {
+                    while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
+                }
+                fwd8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
+            }
+            const uint32_t broom = bwd8 < room ? bwd8 : room;
+            // ---- the greedy walk: tokens stay in their probe lane until the block is done ----------------------
+            uint64_t evmask = 0;
+            uint32_t tk = 0;            // start | len << 16 of the token found at this lane's probe
+            for (;;) {
+                const uint32_t pend = q - B;                            // j - backRefEnd (:404)
+                const uint32_t bq = broom < pend ? broom : pend;
+                const uint64_t m = ballot(has && q >= nextProbe && fwd8 + bq >= 4);   // :406-407
+                if (!m) break;
+                const int e = __builtin_ctzll(m);
+                const uint32_t qe = base + (uint32_t)e;
+                uint32_t fwd = readlane(fwd8, e);
+                uint32_t bw = readlane(bq, e);
+                if (fwd == 8 || bw == 8) {                              // rare: a length is "8 or more"
+                    const uint32_t ce = readlane(c, e);
+                    if (fwd == 8) fwd = wave_extend_match<SAFE>(src, qe, ce, ZZ_MAX_LEN, end);    // remain(), :64-90
+                    const uint32_t re = readlane(room, e), pe = qe - B;
+                    const uint32_t blim = re < pe ? re : pe;
+                    if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
+                }
+                uint32_t mlen = fwd + bw;
+                if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                           // :412-415
+                const uint32_t ms = qe - bw;                                                        // :416
+                if (lane == e) tk = ms | (mlen << 16);                                              // :420
+                evmask |= 1ull << e;
+                B = ms + mlen;                                                                      // :422
+                nextProbe = B + 1;                                                                  // :424
+                if (nextProbe >= base + 64) break;
+            }
+            // ---- publish this block's tokens and their bitmap bits, all event lanes at once ----------------
+            if (evmask) {
+                const bool ev = (evmask >> lane) & 1;
+                if (ev) {
+                    const uint32_t ms = tk & 0xFFFF, mlen = tk >> 16;
+                    l2_token t; t.start = (uint16_t)ms; t.dist = (uint16_t)(q - c); t.len = (uint16_t)mlen; t.pad = 0;
+                    tokens[ntok + (uint32_t)__builtin_popcountll(evmask & ((1ull << lane) - 1))] = t;
+                    const uint32_t last = ms + mlen - 1;
+                    for (uint32_t wi = ms >> 6; wi <= (last >> 6); ++wi) {
+                        const uint32_t lo = wi == (ms >> 6) ? (ms & 63) : 0;
+                        const uint32_t hi = wi == (last >> 6) ? (last & 63) : 63;
+                        const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
+                        atomicOr((unsigned long long*)&cov[wi], (unsigned long long)mask);
+                    }
+                    atomicOr((unsigned long long*)&mst[ms >> 6], 1ull << (ms & 63));
+                }
+                ntok += (uint32_t)__builtin_popcountll(evmask);
+            }
+        }
+        w4 = w4next;
+    }
+    return ntok;
+}
+
 struct zz_l2_params {
     zz_packet_params pk;
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
@@ -304,6 +426,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
     uint16_t* rle = (uint16_t*)(lds + 7344);       // up to 316+30 records -> 704 bytes
 
     const int lane = lane_id();
+    ZZ_PROF_DECL
     l2_token* tokens = (l2_token*)(Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES);
 
     for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
@@ -330,109 +453,16 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
             zz_cks c = wave_adler(src, len);
             if (lane == 0) P.cks[k] = c;
         }
+        ZZ_T(0);
 
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-440) ===========================================
-            const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
-            uint32_t ntok = 0;
-            uint32_t B = 1;                 // backRefEnd (:380)
-            uint32_t nextProbe = 1;         // j (:383)
-            uint32_t batchEnd = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
-            uint32_t skipPos = 0;           // position that must not be inserted in the current block (0 = byte 0)
-            for (uint32_t base = 0; base < target; base += 64) {
-                if (base >= batchEnd) {
-                    // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first
-                    // byte is inserted only if the last match covered it
-                    const uint32_t s2 = B > batchEnd ? B : batchEnd;
-                    skipPos = B >= batchEnd ? 0xFFFFFFFFu : batchEnd;
-                    B = s2 + 1;
-                    nextProbe = s2 + 1;
-                    const uint32_t rest = target - s2;
-                    batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
-                }
-                const uint32_t q = base + lane;
-                const bool ins = q < n && q != skipPos && q != 0;
-                const uint32_t w4 = q < n ? load32_safe(src + q, end) : 0;
-                const uint32_t h = calc_hash3(w4);                            // CalcHash(source + j), :388
-                uint32_t old = 0;
-                if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1); }            // :389-390 / :474-480
-                __syncthreads();
-                const bool lost = ins && T[h] != (uint16_t)(q + 1);
-                uint64_t lostmask = ballot(lost);
-                uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
-                while (lostmask) {
-                    const int l0 = __builtin_ctzll(lostmask);
-                    const uint32_t hv = readlane(h, l0);
-                    const bool mine = ins && h == hv;
-                    const uint64_t set = ballot(mine);
-                    const uint64_t below = set & ((1ull << lane) - 1);
-                    if (mine && below) cand1 = base + (63 - __builtin_clzll(below)) + 1;   // nearest earlier member
-                    if (mine && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);          // highest member wins
-                    lostmask &= ~set;
-                }
-                skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
+            // loads may run a few bytes past the packet: only the last two packets can leave the buffer that way
+            const uint32_t ntok = k + 2 >= P.npk ? l2_token_pass<true>(T, cov, mst, tokens, src, end, n, before)
+                                                 : l2_token_pass<false>(T, cov, mst, tokens, src, end, n, before);
+            __syncthreads();   // token stores (global) are read back by other lanes below
 
-                if (base + 64 > nextProbe && nextProbe < batchEnd) {
-                    // ---- quick compare info for all 64 probes of this block --------------------------------------
-                    const bool has = ins && cand1 != 0 && q < batchEnd;
-                    const uint32_t c = cand1 - 1;
-                    uint32_t fwd8 = 0, bwd8 = 0, room = 0;
-                    if (has) {
-                        const uint64_t x = load64_safe(src + q, end) ^ load64_safe(src + c, end);   // :399
-                        fwd8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
-                        const uint64_t cb = before + c;                        // bytes in front of the candidate
-                        room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
-                        if (room >= 8) {
-                            const uint64_t y = load64(src + (int64_t)q - 8) ^ load64(src + (int64_t)c - 8);
-                            bwd8 = y ? (uint32_t)__builtin_clzll(y) >> 3 : 8;
-                        } else {
-                            while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
-                        }
-                    }
-                    // ---- the greedy walk --------------------------------------------------------------------------
-                    for (;;) {
-                        const uint32_t pend = q - B;                            // j - backRefEnd (:404)
-                        uint32_t bq = bwd8 < room ? bwd8 : room;
-                        bq = bq < pend ? bq : pend;
-                        const bool pred = has && q >= nextProbe && fwd8 + bq >= 4;   // :406-407
-                        const uint64_t m = ballot(pred);
-                        if (!m) break;
-                        const int e = __builtin_ctzll(m);
-                        const uint32_t qe = base + (uint32_t)e;
-                        const uint32_t ce = readlane(c, e);
-                        uint32_t fwd = readlane(fwd8, e);
-                        if (fwd == 8) fwd = wave_extend_match<true>(src, qe, ce, ZZ_MAX_LEN, end);          // remain(), :64-90
-                        uint32_t bw = readlane(bq, e);
-                        const uint32_t blim = readlane(room < pend ? room : pend, e);
-                        if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
-                        uint32_t mlen = fwd + bw;
-                        if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                       // :412-415
-                        const uint32_t ms = qe - bw;                                                    // :416
-                        if (lane == 0) {
-                            l2_token t; t.start = (uint16_t)ms; t.dist = (uint16_t)(qe - ce); t.len = (uint16_t)mlen; t.pad = 0;
-                            tokens[ntok] = t;                                                           // :420
-                        }
-                        ntok++;
-                        // status bitmaps: bits [ms, ms+mlen) covered, bit ms = match start
-                        {
-                            const uint32_t w0 = ms >> 6, w1 = (ms + mlen - 1) >> 6;
-                            const uint32_t wi = w0 + lane;
-                            if (wi <= w1) {
-                                const uint32_t lo = wi == w0 ? (ms & 63) : 0;
-                                const uint32_t hi = wi == w1 ? ((ms + mlen - 1) & 63) : 63;
-                                const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
-                                atomicOr((unsigned long long*)&cov[wi], (unsigned long long)mask);
-                            }
-                            if (lane == 0) atomicOr((unsigned long long*)&mst[w0], 1ull << (ms & 63));
-                        }
-                        B = ms + mlen;                                                                  // :422
-                        nextProbe = B + 1;                                                              // :424
-                        if (nextProbe >= base + 64) break;
-                    }
-                }
-            }
-            __syncthreads();
-
+            ZZ_T(1); ZZ_C(10, 1); ZZ_C(11, ntok);
             // ================= histograms (encoder.cpp:442-471) ===============================================
             const uint32_t nblk = (n + 63) >> 6;
             {   // exclusive scan of per-block match counts
@@ -446,23 +476,38 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
                 }
             }
             __syncthreads();
-            for (uint32_t b = 0; b < nblk; ++b) {
-                const uint64_t cw = cov[b], mw = mst[b];
-                const uint32_t q = (b << 6) + lane;
-                if (q < n) {
-                    if (!((cw >> lane) & 1)) atomicAdd(&symF[src[q]], 1u);
-                    else if ((mw >> lane) & 1) {
-                        const l2_token t = tokens[mcount[b] + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+            for (uint32_t b0 = 0; b0 < nblk; b0 += 4) {
+                // four blocks per trip: all loads first, so that their latencies overlap
+                uint32_t byte[4]; uint32_t kind[4]; l2_token tk4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t b = b0 + i;
+                    const uint32_t q = (b << 6) + lane;
+                    kind[i] = 0; byte[i] = 0; tk4[i].start = 0; tk4[i].dist = 1; tk4[i].len = 3; tk4[i].pad = 0;
+                    if (b < nblk && q < n) {
+                        const uint64_t cw = cov[b], mw = mst[b];
+                        if (!((cw >> lane) & 1)) { kind[i] = 1; byte[i] = src[q]; }
+                        else if ((mw >> lane) & 1) {
+                            kind[i] = 2;
+                            tk4[i] = tokens[mcount[b] + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (kind[i] == 1) atomicAdd(&symF[byte[i]], 1u);
+                    else if (kind[i] == 2) {
                         uint32_t sym, eb, ev, bucket;
-                        length_symbol(t.len, sym, eb, ev);
+                        length_symbol(tk4[i].len, sym, eb, ev);
                         atomicAdd(&symF[sym], 1u);
-                        dist_symbol(t.dist, bucket, eb, ev);
+                        dist_symbol(tk4[i].dist, bucket, eb, ev);
                         atomicAdd(&distF[bucket], 1u);
                     }
                 }
             }
             __syncthreads();
 
+            ZZ_T(2);
             // ================= code construction (lane 0) =====================================================
             if (lane == 0) {
                 symF[256] += 1;                                                  // :470
@@ -491,6 +536,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
                 misc[2] = (uint32_t)nrec;
             }
             __syncthreads();
+            ZZ_T(3);
             const uint32_t required = misc[0];
             const uint32_t nrec = misc[2];
 
@@ -523,6 +569,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
                 generate_codes(metaLens, 19, metaCodes, misc + 16);
             }
             __syncthreads();
+            ZZ_T(4);
             // StartBlock(UserDefinedHuffman, final) + HLIT=29 HDIST=29 HCLEN=15 (:280-285)
             ring_append_uniform(ring, (is_final ? 1u : 0u) | (2u << 1) | (29u << 3) | (29u << 8) | (15u << 13), 17);
             {   // 19 x 3 bits in `order` (:287-290)
@@ -594,7 +641,9 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
             P.sizes[k] = bytes;
             if (bytes > P.slot_stride) atomicOr(P.err, 1u);
         }
+        ZZ_T(5);
     }
+    ZZ_PROF_FLUSH(P);
 }
 
 static inline uint32_t l2_grid(uint32_t npk)

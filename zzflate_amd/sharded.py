@@ -1,0 +1,79 @@
+"""Multi-GPU join of a packet-sharded stream (replaces the reference's in-process
+std::async fan-out + memmove join, zzflate.cpp:97-155, across devices).
+
+Packets are independent and every non-final packet ends byte-aligned, so ranks own contiguous packet ranges
+and the shard outputs concatenate by plain byte copy. The only exchange is
+  1. an all-gather of (compressed bytes, checksum partial, input bytes) per rank, and
+  2. ONE gather of the variable-size compressed shards onto rank 0, as a grouped send/recv (RCCL has no
+     gatherv); compressed bytes travel, never input bytes.
+Rank 0 then adds the container header and the trailer from the combined checksums.
+
+Backend-agnostic: `nccl` (= RCCL over xGMI) with device tensors in bench.py, `gloo` with CPU tensors in the
+tests. The per-shard encoder is whatever the caller ran (Context.encode_shard on a GPU).
+"""
+import torch
+
+from . import Format, combine, crc32_combine, header, trailer
+
+
+def shard_range(total_n, packet_size, rank, world):
+    """Contiguous packet range of `rank`: returns (byte offset, byte count); boundaries are packet-aligned."""
+    npk = (total_n + packet_size - 1) // packet_size
+    per = (npk + world - 1) // world
+    lo = min(rank * per * packet_size, total_n)
+    hi = min((rank + 1) * per * packet_size, total_n)
+    return lo, hi - lo
+
+
+def combine_checksums(fmt, parts):
+    """parts: [(checksum partial, input bytes)] in rank order -> the stream's Adler-32 / CRC-32 (or 0)."""
+    fmt = int(fmt)
+    if fmt == Format.Zlib:
+        tot = 1                                   # adler32x(1, ...): zzflate.cpp:176
+        for cks, n in parts:
+            tot = combine(tot, cks, n)            # adler.cpp:5-15 semantics
+        return tot
+    if fmt == Format.Gzip:
+        tot = 0
+        for cks, n in parts:
+            tot = crc32_combine(tot, cks, n)
+        return tot
+    return 0
+
+
+def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None):
+    """Collective. `shard[:shard_bytes]` is this rank's compressed shard (uint8 tensor), `cks` its checksum
+    partial, `n_in` its input byte count. On rank 0 returns the total stream length written into `out`
+    (header + shards + trailer); elsewhere returns None."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = shard.device
+    meta = torch.tensor([shard_bytes, cks, n_in], dtype=torch.int64, device=dev)
+    metas = torch.empty(3 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    m = metas.cpu().tolist()
+    sizes, ckss, lens = m[0::3], m[1::3], m[2::3]
+    head = header(fmt)
+    ops, off = [], len(head)
+    offs = []
+    for r in range(world):
+        offs.append(off)
+        off += sizes[r]
+    if rank == 0:
+        assert out is not None and out.numel() >= off + 8, "rank 0 needs an output buffer"
+        for r in range(1, world):
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r] + sizes[r]], r, group))
+        out[offs[0]:offs[0] + sizes[0]].copy_(shard[:sizes[0]])
+    elif sizes[rank]:
+        ops.append(dist.P2POp(dist.isend, shard[:sizes[rank]], 0, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != 0:
+        return None
+    tail = trailer(fmt, combine_checksums(fmt, list(zip(ckss, lens))), sum(lens))
+    if head:
+        out[:len(head)].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
+    if tail:
+        out[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
+    return off + len(tail)
