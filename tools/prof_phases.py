@@ -34,9 +34,10 @@ if level >= 2:
     for i, nm in enumerate(names):
         print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
     sys.exit(0)
-names = ["adler+init", "hash", "probe+dups", "len/info VALU", "walk", "repair", "codes", "ring_append", "tail", "wait cand+w loads"]
-tot = sum(prof[:10])
-print(f"input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; groups {prof[10]}, events {prof[11]}, extensions {prof[12]}")
+names = ["loop top", "hash+probe issue", "emit prev group", "readback+dup loop", "wait cand load", "info VALU", "walk", "repair+pack", "wait wnext"]
+tot = sum(prof[:9])
+print(f"input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; groups {prof[10]}, events {prof[11]}, simple events {prof[12]}")
+print(f"complex events/group: hard {prof[12]/max(1,prof[10]):.3f} dup {prof[13]/max(1,prof[10]):.3f} ext-only {prof[14]/max(1,prof[10]):.3f}; dup sets/group {prof[15]/max(1,prof[10]):.3f}")
 print(f"bytes/group {n / max(1, prof[10]):.1f}, events/group {prof[11] / max(1, prof[10]):.2f}, cycles/group {tot / max(1, prof[10]):.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:16s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):8.0f} cyc/group")

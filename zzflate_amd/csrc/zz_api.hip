@@ -214,7 +214,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof;
 
         if (cks_kind == ZZ_CKS_CRC) {
-            uint32_t g = npk < 65536 ? npk : 65536;
+            uint32_t g = npk < 2048 ? npk : 2048;   // persistent: table + shift constants are built once per block
             hipLaunchKernelGGL(k_crc32_packets, dim3(g), dim3(ZZ_CRC_THREADS), 0, st, pp);
             pp.cks_kind = ZZ_CKS_NONE;   // the encode kernel must not overwrite the CRC partials
         }

@@ -102,6 +102,15 @@ __global__ __launch_bounds__(ZZ_CRC_THREADS) void k_crc32_packets(zz_packet_para
         tab[t][tid] = (c >> 8) ^ tab[0][c & 0xFF];
     }
     __syncthreads();
+    // x^(8 * bytes after my slice) for a full packet: the same for every full packet, so computed once
+    uint32_t shift_full;
+    {
+        const uint32_t len = P.packet_size;
+        const uint32_t slice = ((len + ZZ_CRC_THREADS - 1) / ZZ_CRC_THREADS + 3) & ~3u;
+        uint32_t b1 = tid * slice + slice;
+        if (b1 > len) b1 = len;
+        shift_full = gf2_xpow8(len - b1);
+    }
     for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
         const uint64_t off = (uint64_t)k * P.packet_size;
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(ZZ_CRC_THREADS) void k_crc32_packets(zz_packet_para
             }
             for (; i < b1; ++i) c = (c >> 8) ^ tab[0][(c & 0xFF) ^ p[i]];   // crc.cpp:28-31
             c = ~c;
-            c = gf2_mulmod(c, gf2_xpow8(len - b1));
+            c = gf2_mulmod(c, len == P.packet_size ? shift_full : gf2_xpow8(len - b1));
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) c ^= __shfl_xor(c, o);
@@ -164,18 +173,27 @@ __global__ __launch_bounds__(ZZ_RED_THREADS) void k_cks_reduce(const zz_cks* cks
         }
         len += l;
     }
+    if (kind == ZZ_CKS_CRC) {
+        // CRC folds linearly: total = XOR over runs of crc_run * x^(8 * bytes after the run), all runs in parallel
+        const uint64_t after = n - ((uint64_t)k1 * packet_size < n ? (uint64_t)k1 * packet_size : n);
+        a = len ? gf2_mulmod((uint32_t)a, gf2_xpow8(after)) : 0;
+    }
     sa[t] = (uint32_t)a; sb[t] = (uint32_t)b; sl[t] = len;
     __syncthreads();
+    if (kind == ZZ_CKS_CRC) {
+        for (uint32_t d = ZZ_RED_THREADS / 2; d >= 1; d >>= 1) {
+            if (t < d) sa[t] ^= sa[t + d];
+            __syncthreads();
+        }
+        if (t == 0) { out->a = sa[0]; out->b = 0; out->len = n; }
+        return;
+    }
     if (t == 0) {
         uint64_t A = 0, B = 0, L = 0;
         for (uint32_t i = 0; i < ZZ_RED_THREADS; ++i) {
             if (sl[i] == 0) continue;
-            if (kind == ZZ_CKS_ADLER) {
-                B = (B + sb[i] + (sl[i] % ZZ_ADLER_MOD) * A) % ZZ_ADLER_MOD;
-                A = (A + sa[i]) % ZZ_ADLER_MOD;
-            } else {
-                A = gf2_mulmod((uint32_t)A, gf2_xpow8(sl[i])) ^ sa[i];
-            }
+            B = (B + sb[i] + (sl[i] % ZZ_ADLER_MOD) * A) % ZZ_ADLER_MOD;   // adler.cpp:5-15 combine
+            A = (A + sa[i]) % ZZ_ADLER_MOD;
             L += sl[i];
         }
         out->a = (uint32_t)A; out->b = (uint32_t)B; out->len = L;

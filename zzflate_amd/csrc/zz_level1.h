@@ -74,6 +74,40 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 #define ZZ_WI_EXTA 0x10000u                  // lenA is "8 or more" and more bytes remain: extend
 #define ZZ_WI_EXTB 0x20000u
 
+// The inner loop of the walk, for runs of "simple" matches (length known, candidate independent of the parse).
+//   E  : lanes that may start a match          Ms : the simple ones among them      la : their lengths (VGPR)
+//   pos: first lane not yet decided            mst: match-start lanes so far        cov: lanes inside matches
+// Leaves when the next event is not simple, when there is none, or when pos reaches 64.
+__device__ __forceinline__ void l1_fast_walk(uint64_t E, uint64_t Ms, uint32_t la, uint32_t& pos, uint64_t& mst,
+                                             uint64_t& cov)
+{
+    uint64_t tmp;
+    int32_t e;
+    uint32_t t;
+    asm volatile(
+        "s_cmp_lt_u32 %[pos], 64\n\t"
+        "s_cbranch_scc0 2f\n"
+        "1:\n\t"
+        "s_lshl_b64 %[tmp], -1, %[pos]\n\t"
+        "s_and_b64 %[tmp], %[tmp], %[E]\n\t"
+        "s_ff1_i32_b64 %[e], %[tmp]\n\t"          // first event at or after pos (-1: none)
+        "s_cmp_lt_i32 %[e], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_bitcmp1_b64 %[Ms], %[e]\n\t"           // simple?
+        "s_cbranch_scc0 2f\n\t"
+        "v_readlane_b32 %[t], %[la], %[e]\n\t"    // its length (encoder.cpp:350-354)
+        "s_bitset1_b64 %[mst], %[e]\n\t"          // a match starts here (encoder.cpp:356)
+        "s_bfm_b64 %[tmp], %[t], %[e]\n\t"        // lanes e .. e+len-1 (len <= 7)
+        "s_or_b64 %[cov], %[cov], %[tmp]\n\t"
+        "s_add_u32 %[pos], %[e], %[t]\n\t"        // encoder.cpp:361-362
+        "s_cmp_lt_u32 %[pos], 64\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [tmp] "=&s"(tmp), [e] "=&s"(e), [t] "=&s"(t)
+        : [E] "s"(E), [Ms] "s"(Ms), [la] "v"(la)
+        : "scc");
+}
+
 // a committed token as it waits one iteration for emission: bit31 match (len<<16 | dist), bit30 literal (byte)
 #define ZZ_TOK_MATCH 0x80000000u
 #define ZZ_TOK_LIT 0x40000000u
@@ -100,6 +134,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
                                                bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n)
 {
     const int lane = lane_id();
+    ZZ_PROF_DECL
     uint32_t cur = 0;
     uint32_t ptok = 0;                                                    // previous group's tokens
     uint64_t w = (uint32_t)lane < n ? ld64<SAFE>(src + lane, end) : 0;    // 8 bytes at this lane's position
@@ -109,6 +144,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         const uint32_t p = cur + lane;
         const bool active = lane < (int)nact;
 
+        ZZ_T(0);
         // (1) hash, probe + speculative insert; the candidate's bytes are requested at once
         const uint32_t h = calc_hash3((uint32_t)(w >> 8));              // bytes p+1..p+3 (encoder.cpp:344)
         uint32_t old = 0;
@@ -122,15 +158,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         uint32_t rb = 0;
         if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
 
+        ZZ_T(1);
         // (1a) the previous group's tokens leave while those loads are in flight
         if (cur) l1_emit_tokens(ring, lcodes, ptok);
 
+        ZZ_T(2);
         // (1b) which lanes share a hash inside the group?
         uint64_t lostmask = ballot(active && rb != ((p + 1) & 0xFFFF));
         uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
         uint32_t info = 0;
         while (lostmask) {
+            ZZ_C(15, 1);
             const int l0 = __builtin_ctzll(lostmask);
             const uint32_t hv = readlane(h, l0);
             const bool mine = active && h == hv;
@@ -147,6 +186,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
             lostmask &= ~set;
         }
 
+        ZZ_T(3);
+        ZZ_DRAIN();
+        ZZ_T(4);
         // (2) lengths against both possible candidates, capped at 8 ("8 or more")
         const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
         const uint32_t cap8 = left < 8 ? left : 8;
@@ -175,66 +217,70 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
         const uint64_t Ms = ballot(active && la >= 4 && !(info & (ZZ_WI_DUP | ZZ_WI_EXTA)));
 
-        // (3) the walk: replays the reference's decisions in order (encoder.cpp:341-368)
-        uint64_t lits = 0, mst = 0, usedB = 0;   // committed literal lanes / match-start lanes / matched the in-group candidate
+        ZZ_T(5); ZZ_C(10, 1);
+        // (3) the walk: replays the reference's decisions in order (encoder.cpp:341-368). Scalar code is slow
+        // on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip), so runs
+        // of "simple" matches go through a hand-written 12-instruction loop; everything else drops out to C++.
+        uint64_t mst = 0, cov = 0, usedB = 0;    // match-start lanes / lanes covered by matches / matched the in-group candidate
         uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events
         uint32_t pos = 0;
         for (;;) {
+            l1_fast_walk(E, Ms, la, pos, mst, cov);
+            if (pos >= nact) break;
             const uint64_t Er = E & (~0ull << pos);
-            if (!Er) { lits |= actmask & (~0ull << pos); pos = nact; break; }
+            if (!Er) { pos = nact; break; }
             const int e = __builtin_ctzll(Er);
-            lits |= ((1ull << e) - 1) & (~0ull << pos);                  // literals pos..e-1 (encoder.cpp:367)
-            if ((Ms >> e) & 1) {
-                mst |= 1ull << e;                                        // encoder.cpp:356
-                pos = (uint32_t)e + readlane(la, e);                     // encoder.cpp:361-362
+            ZZ_C(11, 1);
+            const uint64_t probed = ~cov | mst;                         // lanes below e the parse has visited
+            const uint32_t inf = readlane(info, e);
+            ZZ_C(12, (inf & ZZ_WI_HARD) ? 1 : 0); ZZ_C(13, (inf & ZZ_WI_DUP) ? 1 : 0); ZZ_C(14, (!(inf & ZZ_WI_DUP) && (inf & ZZ_WI_EXTA)) ? 1 : 0);
+            const uint32_t pe = cur + (uint32_t)e;
+            const uint32_t maxlen = (n - pe) < ZZ_MAX_LEN ? (n - pe) : ZZ_MAX_LEN;
+            uint32_t mlen;
+            if (!(inf & ZZ_WI_HARD)) {
+                const bool useB = (inf & ZZ_WI_DUP) && ((probed >> ZZ_WI_QLANE(inf)) & 1);
+                mlen = useB ? ZZ_WI_LENB(inf) : ZZ_WI_LENA(inf);
+                if (mlen >= 4) {
+                    if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
+                        const uint32_t cand = useB ? cur + ZZ_WI_QLANE(inf) : readlane(old, e) - 1;
+                        mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end);
+                        if (lane == e) ovlen = mlen;
+                    }
+                    if (useB) usedB |= 1ull << e;
+                }
             } else {
-                const uint32_t inf = readlane(info, e);
-                const uint32_t pe = cur + (uint32_t)e;
-                const uint32_t maxlen = (n - pe) < ZZ_MAX_LEN ? (n - pe) : ZZ_MAX_LEN;
-                uint32_t mlen;
-                if (!(inf & ZZ_WI_HARD)) {
-                    const bool useB = (inf & ZZ_WI_DUP) && (((lits | mst) >> ZZ_WI_QLANE(inf)) & 1);
-                    mlen = useB ? ZZ_WI_LENB(inf) : ZZ_WI_LENA(inf);
-                    if (mlen >= 4) {
-                        if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
-                            const uint32_t cand = useB ? cur + ZZ_WI_QLANE(inf) : readlane(old, e) - 1;
-                            mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end);
-                            if (lane == e) ovlen = mlen;
-                        }
-                        if (useB) usedB |= 1ull << e;
-                    }
+                // hash shared by 3+ lanes: candidate = most recent visited lane with my hash, else the table's
+                const uint64_t S = readlane64(myset, e) & probed & ((1ull << e) - 1);
+                uint32_t cand1 = 0;
+                uint64_t xe = ~0ull;
+                if (S) {
+                    const int c = 63 - __builtin_clzll(S);
+                    cand1 = cur + (uint32_t)c + 1;
+                    xe = readlane64(w, e) ^ readlane64(w, c);
                 } else {
-                    // hash shared by 3+ lanes: candidate = most recent committed lane with my hash, else the table's
-                    const uint64_t S = readlane64(myset, e) & (lits | mst) & ((1ull << e) - 1);
-                    uint32_t cand1 = 0;
-                    uint64_t xe = ~0ull;
-                    if (S) {
-                        const int c = 63 - __builtin_clzll(S);
-                        cand1 = cur + (uint32_t)c + 1;
-                        xe = readlane64(w, e) ^ readlane64(w, c);
-                    } else {
-                        cand1 = readlane(old, e);
-                        if (cand1) xe = readlane64(x, e);
-                    }
-                    mlen = 0;
-                    if ((uint32_t)xe == 0 && maxlen >= 4) {
-                        if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
-                        else mlen = wave_extend_match<SAFE>(src, pe, cand1 - 1, maxlen, end);
-                        if (mlen > maxlen) mlen = maxlen;
-                    }
-                    if (lane == e) { ovlen = mlen; ovcand1 = cand1; }
+                    cand1 = readlane(old, e);
+                    if (cand1) xe = readlane64(x, e);
                 }
-                if (mlen > 3) {
-                    mst |= 1ull << e;
-                    pos = (uint32_t)e + mlen;
-                } else {
-                    lits |= 1ull << e;
-                    pos = (uint32_t)e + 1;
+                mlen = 0;
+                if ((uint32_t)xe == 0 && maxlen >= 4) {
+                    if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
+                    else mlen = wave_extend_match<SAFE>(src, pe, cand1 - 1, maxlen, end);
+                    if (mlen > maxlen) mlen = maxlen;
                 }
+                if (lane == e) { ovlen = mlen; ovcand1 = cand1; }
+            }
+            if (mlen > 3) {                                              // encoder.cpp:356
+                mst |= 1ull << e;
+                cov |= (mlen >= 64u - (uint32_t)e) ? (~0ull << e) : (((1ull << mlen) - 1) << e);
+                pos = (uint32_t)e + mlen;                                // encoder.cpp:361-362
+            } else {
+                pos = (uint32_t)e + 1;                                   // a literal after all (encoder.cpp:367)
             }
             if (pos >= nact) break;
         }
-        const uint64_t committed = lits | mst;
+        ZZ_T(6);
+        // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
+        const uint64_t committed = (actmask & ~cov & (pos >= 64 ? ~0ull : ((1ull << pos) - 1))) | mst;
         const uint32_t next = cur + pos;
         // next group's bytes: in flight while this group is repaired
         const uint64_t wnext = next + (uint32_t)lane < n ? ld64<SAFE>(src + next + lane, end) : 0;
@@ -263,9 +309,13 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
             }
         }
         cur = next;
+        ZZ_T(7);
+        ZZ_DRAIN();
         w = wnext;
+        ZZ_T(8);
     }
     l1_emit_tokens(ring, lcodes, ptok);
+    ZZ_PROF_FLUSH(P);
 }
 
 __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
