@@ -74,37 +74,75 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 #define ZZ_WI_EXTA 0x10000u                  // lenA is "8 or more" and more bytes remain: extend
 #define ZZ_WI_EXTB 0x20000u
 
-// The inner loop of the walk, for runs of "simple" matches (length known, candidate independent of the parse).
-//   E  : lanes that may start a match          Ms : the simple ones among them      la : their lengths (VGPR)
-//   pos: first lane not yet decided            mst: match-start lanes so far        cov: lanes inside matches
-// Leaves when the next event is not simple, when there is none, or when pos reaches 64.
-__device__ __forceinline__ void l1_fast_walk(uint64_t E, uint64_t Ms, uint32_t la, uint32_t& pos, uint64_t& mst,
-                                             uint64_t& cov)
+// The inner loop of the walk (encoder.cpp:341-368 replayed over ballot masks), hand-written because scalar code
+// is slow on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip).
+//   E    : lanes that may start a match          info : per-lane packed walk info (ZZ_WI_*), VGPR
+//   pos  : first lane not yet decided            mst  : match-start lanes so far
+//   cov  : lanes inside matches so far           usedB: match starts that matched the in-group candidate
+// Handles, without leaving the loop: plain matches (length < 8 against the table candidate) and lanes whose hash
+// occurs twice in the group (candidate = the earlier lane if the parse visited it, else the table's). Leaves
+// with pos unchanged at an event it cannot decide (hash shared by 3+ lanes, or a length of "8 or more" that
+// needs extension); leaves with pos >= 64, or with no event at or after pos, when the group is done.
+__device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t& pos, uint64_t& mst, uint64_t& cov,
+                                             uint64_t& usedB)
 {
     uint64_t tmp;
     int32_t e;
-    uint32_t t;
+    uint32_t inf, len, q;
     asm volatile(
         "s_cmp_lt_u32 %[pos], 64\n\t"
-        "s_cbranch_scc0 2f\n"
+        "s_cbranch_scc0 3f\n"
         "1:\n\t"
         "s_lshl_b64 %[tmp], -1, %[pos]\n\t"
         "s_and_b64 %[tmp], %[tmp], %[E]\n\t"
-        "s_ff1_i32_b64 %[e], %[tmp]\n\t"          // first event at or after pos (-1: none)
+        "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first event at or after pos (-1: none)
         "s_cmp_lt_i32 %[e], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_bitcmp1_b64 %[Ms], %[e]\n\t"           // simple?
-        "s_cbranch_scc0 2f\n\t"
-        "v_readlane_b32 %[t], %[la], %[e]\n\t"    // its length (encoder.cpp:350-354)
-        "s_bitset1_b64 %[mst], %[e]\n\t"          // a match starts here (encoder.cpp:356)
-        "s_bfm_b64 %[tmp], %[t], %[e]\n\t"        // lanes e .. e+len-1 (len <= 7)
+        "s_cbranch_scc1 3f\n\t"
+        "v_readlane_b32 %[inf], %[info], %[e]\n\t"
+        "s_and_b32 %[len], %[inf], 0x1c000\n\t"     // DUP | HARD | EXTA
+        "s_cmp_eq_u32 %[len], 0\n\t"
+        "s_cbranch_scc0 4f\n\t"
+        "s_and_b32 %[len], %[inf], 15\n"            // plain match, length lenA (encoder.cpp:350-354)
+        "5:\n\t"
+        "s_bitset1_b64 %[mst], %[e]\n\t"            // a match starts here (encoder.cpp:356)
+        "s_bfm_b64 %[tmp], %[len], %[e]\n\t"        // lanes e .. e+len-1
         "s_or_b64 %[cov], %[cov], %[tmp]\n\t"
-        "s_add_u32 %[pos], %[e], %[t]\n\t"        // encoder.cpp:361-362
+        "s_add_u32 %[pos], %[e], %[len]\n\t"        // encoder.cpp:361-362
+        "s_cmp_lt_u32 %[pos], 64\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_branch 3f\n"
+        "4:\n\t"
+        "s_bitcmp1_b32 %[inf], 15\n\t"              // HARD: leave
+        "s_cbranch_scc1 3f\n\t"
+        "s_bitcmp1_b32 %[inf], 14\n\t"              // not DUP (so EXTA only): leave
+        "s_cbranch_scc0 3f\n\t"
+        "s_bfe_u32 %[q], %[inf], 0x60008\n\t"       // the earlier lane with my hash
+        "s_bitcmp1_b64 %[mst], %[q]\n\t"            // visited as a match start?
+        "s_cbranch_scc1 6f\n\t"
+        "s_bitcmp0_b64 %[cov], %[q]\n\t"            // visited as a literal?
+        "s_cbranch_scc1 6f\n\t"
+        "s_bitcmp1_b32 %[inf], 16\n\t"              // skipped: the table's candidate; EXTA: leave
+        "s_cbranch_scc1 3f\n\t"
+        "s_and_b32 %[len], %[inf], 15\n\t"
+        "s_cmp_lt_u32 %[len], 4\n\t"
+        "s_cbranch_scc0 5b\n\t"
+        "s_branch 8f\n"
+        "6:\n\t"
+        "s_bitcmp1_b32 %[inf], 17\n\t"              // visited: candidate is lane q; EXTB: leave
+        "s_cbranch_scc1 3f\n\t"
+        "s_bfe_u32 %[len], %[inf], 0x40004\n\t"
+        "s_cmp_lt_u32 %[len], 4\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "s_bitset1_b64 %[usedB], %[e]\n\t"
+        "s_branch 5b\n"
+        "8:\n\t"
+        "s_add_u32 %[pos], %[e], 1\n\t"             // a literal after all (encoder.cpp:367)
         "s_cmp_lt_u32 %[pos], 64\n\t"
         "s_cbranch_scc1 1b\n"
-        "2:\n\t"
-        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [tmp] "=&s"(tmp), [e] "=&s"(e), [t] "=&s"(t)
-        : [E] "s"(E), [Ms] "s"(Ms), [la] "v"(la)
+        "3:\n\t"
+        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e),
+          [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q)
+        : [E] "s"(E), [info] "v"(info)
         : "scc");
 }
 
@@ -215,7 +253,6 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
         const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
-        const uint64_t Ms = ballot(active && la >= 4 && !(info & (ZZ_WI_DUP | ZZ_WI_EXTA)));
 
         ZZ_T(5); ZZ_C(10, 1);
         // (3) the walk: replays the reference's decisions in order (encoder.cpp:341-368). Scalar code is slow
@@ -225,7 +262,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events
         uint32_t pos = 0;
         for (;;) {
-            l1_fast_walk(E, Ms, la, pos, mst, cov);
+            l1_fast_walk(E, info, pos, mst, cov, usedB);
             if (pos >= nact) break;
             const uint64_t Er = E & (~0ull << pos);
             if (!Er) { pos = nact; break; }

@@ -107,7 +107,17 @@ __device__ __forceinline__ void coop_copy(uint8_t* dst, const uint8_t* src, uint
     uint64_t body = (n - head) >> 4;
     const uint8_t* s = src + head;
     uint4* d = (uint4*)(dst + head);
-    for (uint64_t i = tid; i < body; i += nthreads) {
+    uint64_t i = tid;
+    // four independent 16-byte loads in flight per thread, then four aligned stores
+    for (; i + 3 * (uint64_t)nthreads < body; i += 4 * (uint64_t)nthreads) {
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, s + (i << 4), 16);
+        __builtin_memcpy(&v1, s + ((i + nthreads) << 4), 16);
+        __builtin_memcpy(&v2, s + ((i + 2 * (uint64_t)nthreads) << 4), 16);
+        __builtin_memcpy(&v3, s + ((i + 3 * (uint64_t)nthreads) << 4), 16);
+        d[i] = v0; d[i + nthreads] = v1; d[i + 2 * (uint64_t)nthreads] = v2; d[i + 3 * (uint64_t)nthreads] = v3;
+    }
+    for (; i < body; i += nthreads) {
         uint4 v;
         __builtin_memcpy(&v, s + (i << 4), 16);
         d[i] = v;
