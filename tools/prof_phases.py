@@ -18,7 +18,12 @@ kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = mib << 20
 src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
-L.zz_generate_device(h, ci(kind), u64(0x5EED0002), u64(0), vp(src.data_ptr()), u64(n), vp(0))
+if kind == 9:   # real English text: the Canterbury text files tiled (cold table per packet, so tiling is harmless)
+    base = b"".join(open(os.path.join(ROOT, "tests/golden/corpus", f), "rb").read() for f in ("alice29.txt", "asyoulik.txt", "lcet10.txt", "plrabn12.txt"))
+    host = (base * (n // len(base) + 1))[:n]
+    src[:n].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+else:
+    L.zz_generate_device(h, ci(kind), u64(0x5EED0002), u64(0), vp(src.data_ptr()), u64(n), vp(0))
 cap = L.zz_bound(u64(n), ci(0), ci(level), u32(32768))
 dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 out = u64(0)

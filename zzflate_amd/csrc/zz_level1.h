@@ -36,19 +36,32 @@ template <bool SAFE> __device__ __forceinline__ uint64_t ld64(const uint8_t* p, 
     if (SAFE) return load64_safe(p, end);
     return load64(p);
 }
+// 16 bytes at p as two little-endian words
+template <bool SAFE> __device__ __forceinline__ void ld128(const uint8_t* p, const uint8_t* end, uint64_t& lo, uint64_t& hi)
+{
+    if (!SAFE || p + 16 <= end) {
+        uint4 v;
+        __builtin_memcpy(&v, p, 16);
+        lo = ((uint64_t)v.y << 32) | v.x;
+        hi = ((uint64_t)v.w << 32) | v.z;
+    } else {
+        lo = load64_safe(p, end);
+        hi = load64_safe(p + 8, end);
+    }
+}
 template <bool SAFE> __device__ __forceinline__ uint32_t ld32(const uint8_t* p, const uint8_t* end)
 {
     if (SAFE) return load32_safe(p, end);
     return load32(p);
 }
 
-// compare src[pe+8 ..) with src[cand+8 ..) with the whole wave, 4 bytes per lane; returns the match
-// length (>= 8) clamped to maxlen. Only called when the first 8 bytes are known equal.
+// compare src[pe+from ..) with src[cand+from ..) with the whole wave, 4 bytes per lane; returns the match
+// length (>= from) clamped to maxlen. Only called when the first `from` bytes are known equal.
 template <bool SAFE>
 __device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32_t pe, uint32_t cand,
-                                                      uint32_t maxlen, const uint8_t* end)
+                                                      uint32_t maxlen, const uint8_t* end, uint32_t from = 8)
 {
-    const uint32_t o = 8 + 4 * (uint32_t)lane_id();
+    const uint32_t o = from + 4 * (uint32_t)lane_id();
     uint32_t d = 0;
     const bool act = o < maxlen;
     if (act) d = ld32<SAFE>(src + pe + o, end) ^ ld32<SAFE>(src + cand + o, end);
@@ -56,7 +69,7 @@ __device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32
     if (!neq) return maxlen;
     const int k = __builtin_ctzll(neq);
     const uint32_t dk = readlane(d, k);
-    const uint32_t len = 8 + 4 * (uint32_t)k + ((uint32_t)__builtin_ctz(dk) >> 3);
+    const uint32_t len = from + 4 * (uint32_t)k + ((uint32_t)__builtin_ctz(dk) >> 3);
     return len < maxlen ? len : maxlen;
 }
 
@@ -66,23 +79,24 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 }
 
 // per-lane walk info, packed into one VGPR so that the scalar walk needs a single v_readlane per event
-#define ZZ_WI_LENA(i) ((i) & 15u)            // match length vs the table candidate, 8 = "8 or more"
-#define ZZ_WI_LENB(i) (((i) >> 4) & 15u)     // match length vs the nearest earlier same-hash lane
-#define ZZ_WI_QLANE(i) (((i) >> 8) & 63u)    // that lane
-#define ZZ_WI_DUP 0x4000u                    // lane has an earlier same-hash lane in the group
-#define ZZ_WI_HARD 0x8000u                   // its hash occurs more than twice: resolve generically
-#define ZZ_WI_EXTA 0x10000u                  // lenA is "8 or more" and more bytes remain: extend
-#define ZZ_WI_EXTB 0x20000u
+#define ZZ_WI_LENA(i) ((i) & 31u)            // match length vs the table candidate, 16 = "16 or more"
+#define ZZ_WI_LENB(i) (((i) >> 5) & 31u)     // match length vs the nearest earlier same-hash lane
+#define ZZ_WI_QLANE(i) (((i) >> 10) & 63u)   // that lane
+#define ZZ_WI_DUP 0x10000u                   // lane has an earlier same-hash lane in the group
+#define ZZ_WI_HARD 0x20000u                  // its hash occurs more than twice
+#define ZZ_WI_EXTA 0x40000u                  // lenA is "16 or more" and more bytes remain: extend
+#define ZZ_WI_EXTB 0x80000u
+#define ZZ_WI_CAP 16u                        // bytes compared up front (two 8-byte words per lane)
 
 // The inner loop of the walk (encoder.cpp:341-368 replayed over ballot masks), hand-written because scalar code
 // is slow on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip).
 //   E    : lanes that may start a match          info : per-lane packed walk info (ZZ_WI_*), VGPR
 //   pos  : first lane not yet decided            mst  : match-start lanes so far
 //   cov  : lanes inside matches so far           usedB: match starts that matched the in-group candidate
-// Handles, without leaving the loop: plain matches (length < 8 against the table candidate) and lanes whose hash
-// occurs twice in the group (candidate = the earlier lane if the parse visited it, else the table's). Leaves
-// with pos unchanged at an event it cannot decide (hash shared by 3+ lanes, or a length of "8 or more" that
-// needs extension); leaves with pos >= 64, or with no event at or after pos, when the group is done.
+// Handles, without leaving the loop: plain matches (length < 16 against the table candidate) and lanes with an
+// earlier same-hash lane q in the group (candidate = q if the parse visited it; else the table's, provided no
+// third lane shares the hash). Leaves with pos unchanged at an event it cannot decide (q skipped and 3+ lanes
+// share the hash, or a length of "16 or more" that needs extension); leaves with pos >= 64, or with no event at or after pos, when the group is done.
 __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t& pos, uint64_t& mst, uint64_t& cov,
                                              uint64_t& usedB)
 {
@@ -99,10 +113,10 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cmp_lt_i32 %[e], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
         "v_readlane_b32 %[inf], %[info], %[e]\n\t"
-        "s_and_b32 %[len], %[inf], 0x1c000\n\t"     // DUP | HARD | EXTA
+        "s_and_b32 %[len], %[inf], 0x70000\n\t"     // DUP | HARD | EXTA
         "s_cmp_eq_u32 %[len], 0\n\t"
         "s_cbranch_scc0 4f\n\t"
-        "s_and_b32 %[len], %[inf], 15\n"            // plain match, length lenA (encoder.cpp:350-354)
+        "s_and_b32 %[len], %[inf], 31\n"            // plain match, length lenA (encoder.cpp:350-354)
         "5:\n\t"
         "s_bitset1_b64 %[mst], %[e]\n\t"            // a match starts here (encoder.cpp:356)
         "s_bfm_b64 %[tmp], %[len], %[e]\n\t"        // lanes e .. e+len-1
@@ -112,25 +126,25 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cbranch_scc1 1b\n\t"
         "s_branch 3f\n"
         "4:\n\t"
-        "s_bitcmp1_b32 %[inf], 15\n\t"              // HARD: leave
-        "s_cbranch_scc1 3f\n\t"
-        "s_bitcmp1_b32 %[inf], 14\n\t"              // not DUP (so EXTA only): leave
+        "s_bitcmp1_b32 %[inf], 16\n\t"              // not DUP (so EXTA only): leave
         "s_cbranch_scc0 3f\n\t"
-        "s_bfe_u32 %[q], %[inf], 0x60008\n\t"       // the earlier lane with my hash
+        "s_bfe_u32 %[q], %[inf], 0x6000a\n\t"       // the nearest earlier lane with my hash
         "s_bitcmp1_b64 %[mst], %[q]\n\t"            // visited as a match start?
         "s_cbranch_scc1 6f\n\t"
         "s_bitcmp0_b64 %[cov], %[q]\n\t"            // visited as a literal?
         "s_cbranch_scc1 6f\n\t"
-        "s_bitcmp1_b32 %[inf], 16\n\t"              // skipped: the table's candidate; EXTA: leave
+        "s_bitcmp1_b32 %[inf], 17\n\t"              // skipped, and further lanes share the hash (HARD): leave
         "s_cbranch_scc1 3f\n\t"
-        "s_and_b32 %[len], %[inf], 15\n\t"
+        "s_bitcmp1_b32 %[inf], 18\n\t"              // skipped: the table's candidate; EXTA: leave
+        "s_cbranch_scc1 3f\n\t"
+        "s_and_b32 %[len], %[inf], 31\n\t"
         "s_cmp_lt_u32 %[len], 4\n\t"
         "s_cbranch_scc0 5b\n\t"
         "s_branch 8f\n"
         "6:\n\t"
-        "s_bitcmp1_b32 %[inf], 17\n\t"              // visited: candidate is lane q; EXTB: leave
+        "s_bitcmp1_b32 %[inf], 19\n\t"              // visited: the candidate is lane q (the most recent); EXTB: leave
         "s_cbranch_scc1 3f\n\t"
-        "s_bfe_u32 %[len], %[inf], 0x40004\n\t"
+        "s_bfe_u32 %[len], %[inf], 0x50005\n\t"
         "s_cmp_lt_u32 %[len], 4\n\t"
         "s_cbranch_scc1 8f\n\t"
         "s_bitset1_b64 %[usedB], %[e]\n\t"
@@ -175,7 +189,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
     ZZ_PROF_DECL
     uint32_t cur = 0;
     uint32_t ptok = 0;                                                    // previous group's tokens
-    uint64_t w = (uint32_t)lane < n ? ld64<SAFE>(src + lane, end) : 0;    // 8 bytes at this lane's position
+    uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position
+    if ((uint32_t)lane < n) ld128<SAFE>(src + lane, end, w, w2);
     while (cur < n) {
         const uint32_t nact = (n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE;
         const uint64_t actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1);
@@ -190,8 +205,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
             old = T[h];                                                 // encoder.cpp:345
             T[h] = (uint16_t)(p + 1);                                   // encoder.cpp:346
         }
-        uint64_t wc = 0;
-        if (active && old) wc = ld64<SAFE>(src + (old - 1), end);       // encoder.cpp:350
+        uint64_t wc = 0, wc2 = 0;
+        if (active && old) ld128<SAFE>(src + (old - 1), end, wc, wc2);  // encoder.cpp:350
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
         if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
@@ -216,7 +231,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
                 myset = set;
                 const uint64_t below = set & ((1ull << lane) - 1);
                 if (below) {
-                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 8);
+                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 10);
                     if (__builtin_popcountll(set) > 2) info |= ZZ_WI_HARD;
                 }
             }
@@ -227,28 +242,30 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         ZZ_T(3);
         ZZ_DRAIN();
         ZZ_T(4);
-        // (2) lengths against both possible candidates, capped at 8 ("8 or more")
+        // (2) lengths against both possible candidates, capped at 16 ("16 or more")
         const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
-        const uint32_t cap8 = left < 8 ? left : 8;
+        const uint32_t capn = left < ZZ_WI_CAP ? left : ZZ_WI_CAP;
         uint64_t x = ~0ull;
         uint32_t la = 0;
         if (active && old) {
             x = w ^ wc;
-            la = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
-            if (la > cap8) la = cap8;
+            const uint64_t x2 = w2 ^ wc2;
+            la = x ? (uint32_t)__builtin_ctzll(x) >> 3 : (x2 ? 8 + ((uint32_t)__builtin_ctzll(x2) >> 3) : 16);
+            if (la > capn) la = capn;
         }
         info |= la;
-        if (la == 8 && left > 8) info |= ZZ_WI_EXTA;
+        if (la == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTA;
         if (multimask) {
             // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
             const int ql = (info & ZZ_WI_DUP) ? (int)ZZ_WI_QLANE(info) : lane;
             const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), ql) << 32) | (uint32_t)__shfl((int)w, ql);
+            const uint64_t wq2 = ((uint64_t)(uint32_t)__shfl((int)(w2 >> 32), ql) << 32) | (uint32_t)__shfl((int)w2, ql);
             if (info & ZZ_WI_DUP) {
-                const uint64_t xq = w ^ wq;
-                uint32_t lb = xq ? (uint32_t)__builtin_ctzll(xq) >> 3 : 8;
-                if (lb > cap8) lb = cap8;
-                info |= lb << 4;
-                if (lb == 8 && left > 8) info |= ZZ_WI_EXTB;
+                const uint64_t xq = w ^ wq, xq2 = w2 ^ wq2;
+                uint32_t lb = xq ? (uint32_t)__builtin_ctzll(xq) >> 3 : (xq2 ? 8 + ((uint32_t)__builtin_ctzll(xq2) >> 3) : 16);
+                if (lb > capn) lb = capn;
+                info |= lb << 5;
+                if (lb == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTB;
             }
         }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
@@ -280,7 +297,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
                 if (mlen >= 4) {
                     if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
                         const uint32_t cand = useB ? cur + ZZ_WI_QLANE(inf) : readlane(old, e) - 1;
-                        mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end);
+                        mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end, ZZ_WI_CAP);
                         if (lane == e) ovlen = mlen;
                     }
                     if (useB) usedB |= 1ull << e;
@@ -320,7 +337,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         const uint64_t committed = (actmask & ~cov & (pos >= 64 ? ~0ull : ((1ull << pos) - 1))) | mst;
         const uint32_t next = cur + pos;
         // next group's bytes: in flight while this group is repaired
-        const uint64_t wnext = next + (uint32_t)lane < n ? ld64<SAFE>(src + next + lane, end) : 0;
+        uint64_t wnext = 0, wnext2 = 0;
+        if (next + (uint32_t)lane < n) ld128<SAFE>(src + next + lane, end, wnext, wnext2);
 
         // (4) table repair: skipped lanes restore the old entry; among committed lanes sharing a hash the
         // highest position wins -- the state the serial loop leaves behind
@@ -341,7 +359,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
             else {
                 const bool b = (usedB >> lane) & 1;
                 const uint32_t tlen = ovlen ? ovlen : (b ? ZZ_WI_LENB(info) : ZZ_WI_LENA(info));
-                const uint32_t cand1 = (info & ZZ_WI_HARD) ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 : old);
+                const uint32_t cand1 = ovcand1 ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 : old);
                 ptok = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 - cand1);
             }
         }
@@ -349,6 +367,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         ZZ_T(7);
         ZZ_DRAIN();
         w = wnext;
+        w2 = wnext2;
         ZZ_T(8);
     }
     l1_emit_tokens(ring, lcodes, ptok);
