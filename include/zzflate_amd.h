@@ -19,8 +19,9 @@
  * bit-identical to the reference's packet recipe (zzflate.cpp:101-125) wherever that recipe yields a valid
  * DEFLATE encoding, and always valid otherwise. Inputs no longer than one packet therefore produce exactly
  * the reference's single-encoder stream. `threaded == 0` with an input longer than one packet asks for the
- * reference's sequential whole-buffer stream, which is not offered on the device yet: the call fails
- * (error convention below) instead of falling back to a CPU path.
+ * reference's sequential whole-buffer stream: offered on the device at levels 0 and 1 (bit-identical, level 1
+ * on a single wavefront -- a compatibility mode); at levels 2,3 the call fails (error convention below) instead
+ * of falling back to a CPU path.
  *
  * Error convention (zzflate.cpp:229-234): *dest_len = ~0 for a bad level or a destination that cannot hold
  * the container header. This library additionally detects a destination that is too small for the stream
@@ -83,6 +84,13 @@ uint32_t zz_get_packet_size(void);
 /* Whole stream: d_src[0,n) -> d_dst (container header, packets, trailer). *out_len = bytes or ~0. */
 int zz_encode_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                      int format, int level, uint32_t packet_size, void* hip_stream);
+
+/* The reference's sequential whole-buffer stream (threaded == 0, zzflate.cpp:84-95) for device-resident data:
+ * level 0 (stored blocks of 65535 bytes, parallel) and level 1 (one fixed-Huffman block for the whole input,
+ * produced by a single wavefront: bit-identical to the reference, far slower than packet mode; cap must be at
+ * least zz_bound()). n < 2 GiB. Levels 2,3 return ZZ_E_UNSUPPORTED. */
+int zz_encode_stream_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                            int format, int level, void* hip_stream);
 
 /* One shard of a stream (multi-GPU: ranks own contiguous packet ranges). d_src points at the shard's first
  * byte; `halo` bytes in front of it are readable input of the same stream (level >= 2 backward match

@@ -37,6 +37,13 @@ def gpu():
             dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
             w, cks = ctx.encode_shard(buf.data_ptr() + off, n, dst, cap, halo, last, checksum, lvl, P)
             return bytes(dst[:w].cpu().numpy().tobytes()), cks
+        def stream(self, data, fmt, lvl):
+            n = len(data)
+            src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            cap = 2 * n + 1024
+            dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            w = ctx.encode_stream(src, n, dst, cap, fmt, lvl)
+            return bytes(dst[:w].cpu().numpy().tobytes())
     d = Dev()
     d.ctx = ctx
     d.torch = torch
@@ -98,6 +105,27 @@ def test_synth_goldens(gpu, lvl):
             assert h(gpu.encode(synth(kind, int(n), 1), 2, lvl)) == want, key
 
 
+@pytest.mark.parametrize("lvl", [0, 1])
+def test_sequential_stream_matches_reference_goldens(gpu, oracle, corpus, lvl):
+    """threaded=false on more than one packet: the reference's whole-buffer stream (ZzFlateEncode with an ample
+    destination), on the device at levels 0 and 1. Goldens are the reference's own outputs."""
+    for fname in CORPUS_FILES:
+        d = corpus[fname]
+        for fmt in range(3):
+            got = gpu.stream(d, fmt, lvl)
+            assert h(got) == G["files"][fname]["whole"][str(fmt)][str(lvl)], (fname, fmt, lvl)
+    for kind in SYNTH_KINDS:
+        for n in (40000, 70000, 200000):
+            d = synth(kind, n, 3)
+            assert gpu.stream(d, 0, lvl) == oracle.encode(d, 0, lvl), (kind, n, lvl)
+    # through the host entry point with threaded=false
+    d = corpus["alice29.txt"]
+    assert zz.ZzFlateEncode(d, zz.Config(zz.Format.Gzip, lvl, False)) == oracle.encode(d, 1, lvl)
+    with pytest.raises(zz.ZzFlateError) as e:
+        zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 2, False))
+    assert e.value.code == -5
+
+
 def test_empty_input_is_a_valid_stream(gpu):
     """D8: the reference emits no block for empty input (invalid stream); we emit one empty final block."""
     for fmt in range(3):
@@ -135,7 +163,7 @@ def test_host_entry_points(gpu, oracle, corpus):
     small = corpus["grammar.lsp"]
     assert zz.ZzFlateEncode(small, zz.Config(zz.Format.Gzip, 1, False)) == oracle.encode(small, 1, 1)
     with pytest.raises(zz.ZzFlateError):
-        zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, False))   # sequential mode > 1 packet: unsupported
+        zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 3, False))   # sequential mode > 1 packet at level >= 2: unsupported
     with pytest.raises(zz.ZzFlateError):
         zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, True), dest_capacity=100)
 

@@ -72,6 +72,7 @@ def _load():
         "zz_set_packet_size": (i32, [u32]),
         "zz_get_packet_size": (u32, []),
         "zz_encode_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, u32, vp]),
+        "zz_encode_stream_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, vp]),
         "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
         "zz_header": (i32, [i32, vp]),
         "zz_trailer": (i32, [i32, u32, u64, vp]),
@@ -221,6 +222,14 @@ class Context:
         st = self._stream() if stream is None else stream
         _check(lib.zz_encode_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
                                     int(level), packet_size, st))
+        return out.value
+
+    def encode_stream(self, src, n, dst, cap, format=Format.Zlib, level=1, stream=None):
+        """The reference's sequential whole-buffer stream (threaded=false) on the device; levels 0 and 1."""
+        out = ctypes.c_uint64(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_stream_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
+                                           int(level), st))
         return out.value
 
     def encode_shard(self, src, n, dst, cap, halo=0, is_last=True, checksum=Format.Zlib, level=1,

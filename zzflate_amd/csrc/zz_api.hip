@@ -223,7 +223,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             const uint64_t total = (uint64_t)(npk - 1) * l0_packet_bytes(P, false) +
                                    l0_packet_bytes((uint32_t)(n - (uint64_t)(npk - 1) * P), last_is_final);
             if ((uint64_t)hl + total + tl > cap) { set_err("destination too small"); return ZZ_E_NOSPACE; }
-            zz_l0_params q; q.pk = pp; q.dst = d_dst + hl;
+            zz_l0_params q; q.pk = pp; q.dst = d_dst + hl; q.stream_mode = 0;
             uint32_t g = npk < 16384 ? npk : 16384;
             hipLaunchKernelGGL(k_encode_l0, dim3(g), dim3(256), 0, st, q);
             zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
@@ -257,6 +257,106 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
 }
 
 static int cks_kind_for(int format) { return format == ZZ_ZLIB ? ZZ_CKS_ADLER : format == ZZ_GZIP ? ZZ_CKS_CRC : ZZ_CKS_NONE; }
+
+// The reference's sequential whole-buffer stream (threaded=false, zzflate.cpp:84-95) on the device. Level 0 is
+// parallel (stored blocks of 65535 bytes have known places); level 1 is one fixed-Huffman block produced by a
+// single wavefront (k_stream_l1) -- a compatibility mode, bit-identical to the reference, not a fast one.
+static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d_dst, uint64_t cap, int format, int level,
+                         hipStream_t st, zz_result* host_res)
+{
+    if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
+    if (!d_dst || (!d_src && n)) { set_err("null buffer"); return ZZ_E_ARG; }
+    if (n == 0) return encode_common(c, d_src, 0, 0, true, d_dst, cap, format, cks_kind_for(format), true, level, ZZ_DEFAULT_PACKET, st, host_res);
+    if (n >= (1ull << 31)) { set_err("sequential stream: input must be < 2 GiB (the reference funnels lengths through int)"); return ZZ_E_ARG; }
+    if (level >= 2) {
+        set_err("threaded=false (sequential whole-buffer stream) at level >= 2 is only available for inputs of at most one "
+                "packet on the device; use threaded=true");
+        return ZZ_E_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int hl = header_len(format), tl = trailer_len(format);
+    if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
+    const int cks_kind = cks_kind_for(format);
+    c->have_time = false;
+    HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(zz_result), st));
+    HIPCHK(hipMemsetAsync(c->d_cks_total, 0, sizeof(zz_cks_total), st));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), st));
+    zz_packet_params pp;
+    memset(&pp, 0, sizeof pp);
+    pp.src = d_src; pp.n = n; pp.halo = 0; pp.last_is_final = 1; pp.err = c->d_err; pp.prof = c->d_prof;
+    if (level == 0) {
+        const uint32_t B = 0xFFFF;                                     // encoder.cpp:484
+        const uint32_t npk = (uint32_t)((n + B - 1) / B);
+        int rc = ensure_workspace(c, 0, npk, 0);
+        if (rc) return rc;
+        const uint64_t total = (uint64_t)(npk - 1) * (B + 5) + 5 + (n - (uint64_t)(npk - 1) * B);
+        if ((uint64_t)hl + total + tl > cap) { set_err("destination too small"); return ZZ_E_NOSPACE; }
+        pp.packet_size = B; pp.npk = npk; pp.cks_kind = cks_kind; pp.sizes = c->sizes; pp.cks = c->cks;
+        if (cks_kind == ZZ_CKS_CRC) {
+            hipLaunchKernelGGL(k_crc32_packets, dim3(npk < 2048 ? npk : 2048), dim3(ZZ_CRC_THREADS), 0, st, pp);
+            pp.cks_kind = ZZ_CKS_NONE;
+        }
+        zz_l0_params q; q.pk = pp; q.dst = d_dst + hl; q.stream_mode = 1;
+        hipLaunchKernelGGL(k_encode_l0, dim3(npk < 16384 ? npk : 16384), dim3(256), 0, st, q);
+        zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
+        HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
+        if (cks_kind != ZZ_CKS_NONE)
+            hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk, B, n, cks_kind, c->d_cks_total);
+    } else {
+        // one block for the whole input needs bitsAvailable/9 - 8 >= n (encoder.cpp:331-337); a smaller destination
+        // would make the reference cut several blocks, which this mode does not reproduce
+        const uint64_t avail = cap - hl;
+        if (avail < 2 || ((avail - 1) * 8) / 9 < n + 8) {
+            set_err("sequential level-1 stream needs a destination of at least zz_bound() bytes");
+            return ZZ_E_NOSPACE;
+        }
+        const uint64_t bound = ((uint64_t)9 * n + 17) / 8 + 64;
+        const uint32_t P = 32768, npk_c = (uint32_t)((n + P - 1) / P);   // checksum chunks
+        int rc = ensure_workspace(c, 0, npk_c, 0);
+        if (rc) return rc;
+        if (bound > c->slots_cap) {
+            (void)hipFree(c->slots); c->slots = nullptr; c->slots_cap = 0;
+            HIPCHK(hipMalloc(&c->slots, bound));
+            c->slots_cap = bound;
+        }
+        pp.packet_size = P; pp.npk = npk_c; pp.cks_kind = cks_kind; pp.cks = c->cks; pp.sizes = c->sizes;
+        if (cks_kind == ZZ_CKS_CRC) hipLaunchKernelGGL(k_crc32_packets, dim3(npk_c < 2048 ? npk_c : 2048), dim3(ZZ_CRC_THREADS), 0, st, pp);
+        else if (cks_kind == ZZ_CKS_ADLER) hipLaunchKernelGGL(k_adler_packets, dim3(npk_c < 4096 ? npk_c : 4096), dim3(ZZ_WAVE), 0, st, pp);
+        zz_packet_params ps = pp;
+        ps.npk = 1; ps.slots = c->slots; ps.slot_stride = (uint32_t)bound; ps.cks_kind = ZZ_CKS_NONE;
+        if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));
+        hipLaunchKernelGGL(k_stream_l1, dim3(1), dim3(ZZ_WAVE), 0, st, ps);
+        if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
+        hipLaunchKernelGGL(k_copy_stream, dim3(1024), dim3(256), 0, st, c->slots, c->sizes, d_dst + hl,
+                           cap >= (uint64_t)(hl + tl) ? cap - hl - tl : 0, c->d_res);
+        if (cks_kind != ZZ_CKS_NONE)
+            hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk_c, P, n, cks_kind, c->d_cks_total);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, d_dst, cap, format, c->d_cks_total, n, c->d_res);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(zz_result), hipMemcpyDeviceToHost, st));
+    uint32_t kerr = 0;
+    HIPCHK(hipMemcpyAsync(&kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *host_res = *c->h_res;
+    if (kerr) { set_err("internal: output slot overflow"); return ZZ_E_NOSPACE; }
+    if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    return ZZ_OK;
+}
+
+extern "C" int zz_encode_stream_device(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                                       int format, int level, void* hip_stream)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    zz_result r;
+    int rc = encode_stream(c, (const uint8_t*)d_src, n, (uint8_t*)d_dst, cap, format, level, (hipStream_t)hip_stream, &r);
+    if (rc) return rc;
+    *out_len = r.total_bytes;
+    return ZZ_OK;
+}
+
 
 extern "C" int zz_encode_device(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                                 int format, int level, uint32_t P, void* hip_stream)
@@ -391,18 +491,15 @@ static int encode_host_to_stage(zz_ctx* c, const uint8_t* src, uint64_t n, const
     const int level = cfg->level;
     if (level < 0 || level > 3) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
     const uint32_t P = zz_get_packet_size();
-    if (!cfg->threaded && n > P) {
-        set_err("threaded=false (sequential whole-buffer stream) is only available for inputs of at most one "
-                "packet on the device; use threaded=true");
-        return ZZ_E_UNSUPPORTED;
-    }
     int format = cfg->format;
     if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    const bool sequential = !cfg->threaded && n > P;   // more than one packet: the reference's whole-buffer stream
     const uint64_t bound = zz_bound(n, format, level, P);
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_stage(c, n, bound);
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpy(c->stage_in, src, n, hipMemcpyHostToDevice));
+    if (sequential) return zz_encode_stream_device(c, c->stage_in, n, c->stage_out, bound, total, format, level, nullptr);
     return zz_encode_device(c, c->stage_in, n, c->stage_out, bound, total, format, level, P, nullptr);
 }
 

@@ -82,6 +82,17 @@ __device__ __forceinline__ zz_cks wave_adler(const uint8_t* p, uint32_t len)
     return r;
 }
 
+// ---- Adler-32 per chunk as its own kernel (only the sequential-stream mode needs it: the packet kernels fuse it)
+__global__ __launch_bounds__(ZZ_WAVE) void k_adler_packets(zz_packet_params P)
+{
+    for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
+        const uint64_t off = (uint64_t)k * P.packet_size;
+        const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
+        zz_cks c = wave_adler(P.src + off, len);
+        if (lane_id() == 0) P.cks[k] = c;
+    }
+}
+
 // ---- CRC-32 per packet (sibling kernel; gzip container only) ------------------------------------------
 // 256 threads per packet; each thread runs slicing-by-4 over a contiguous slice from LDS tables, then the
 // packet CRC is the XOR over threads of crc_t * x^(8 * bytes after slice t).

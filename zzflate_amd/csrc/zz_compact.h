@@ -55,6 +55,20 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t* slots, uint32_t 
         coop_copy(dst + offsets[k], slots + (uint64_t)k * slot_stride, sizes[k], threadIdx.x, blockDim.x);
 }
 
+// one big copy (the sequential-stream mode has a single 'packet'): 64 KiB per workgroup trip
+__global__ __launch_bounds__(256) void k_copy_stream(const uint8_t* src, const uint32_t* size, uint8_t* dst, uint64_t dst_cap,
+                                                     zz_result* res)
+{
+    const uint64_t n = *size;
+    if (n > dst_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&res->err, 2u);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) res->stream_bytes = n;
+    for (uint64_t off = (uint64_t)blockIdx.x << 16; off < n; off += (uint64_t)gridDim.x << 16)
+        coop_copy(dst + off, src + off, n - off < 65536 ? n - off : 65536, threadIdx.x, blockDim.x);
+}
+
 // header (zzflate.cpp:28-48) + trailer (zzflate.cpp:170-192) around a finished stream; one thread.
 //   zlib : 78 01 ... adler32x(1, src, n) big-endian
 //   gzip : 1f 8b 08 00 00000000 00 ff ... crc32 LE, (uint32)n LE

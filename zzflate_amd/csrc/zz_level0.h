@@ -20,6 +20,8 @@ __host__ __device__ inline uint64_t l0_packet_bytes(uint32_t len, bool is_final)
 struct zz_l0_params {
     zz_packet_params pk;
     uint8_t* dst;          // final destination of the first packet of this shard
+    int stream_mode;       // 1: the reference's sequential stream (threaded=false): stored blocks of pk.packet_size
+                           //    (= 65535, encoder.cpp:484) with no alignment blocks; only the last one is final
 };
 
 __device__ __forceinline__ void put_stored_header(uint8_t* d, uint32_t final, uint32_t n)
@@ -77,11 +79,11 @@ __global__ __launch_bounds__(256) void k_encode_l0(zz_l0_params Q)
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
         const bool is_final = P.last_is_final && k == P.npk - 1;
         const uint8_t* src = P.src + off;
-        uint8_t* d = Q.dst + (uint64_t)k * l0_packet_bytes(P.packet_size, false);
+        uint8_t* d = Q.dst + (uint64_t)k * (Q.stream_mode ? (uint64_t)P.packet_size + 5 : l0_packet_bytes(P.packet_size, false));
         uint32_t A = 0;
         uint64_t C = 0;      // Adler-32 partial sums of this thread's bytes (the copy and the checksum share one read)
-        if (is_final) {
-            if (tid == 0) put_stored_header(d, 1, len);
+        if (is_final || Q.stream_mode) {
+            if (tid == 0) put_stored_header(d, is_final ? 1 : 0, len);
             coop_copy_adler(d + 5, src, len, tid, blockDim.x, 0, want, A, C);
         } else {
             uint8_t* tail = d;

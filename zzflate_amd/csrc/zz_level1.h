@@ -181,8 +181,11 @@ __device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lc
     ring_append(ring, bits, nb);
 }
 
-template <bool SAFE>
-__device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16_t* T, const uint32_t* lcodes,
+// TT = uint16_t: packet mode, positions < 32768, every candidate is within reach.
+// TT = uint32_t: the sequential whole-buffer stream (threaded=false, one block for the whole input): positions up
+//      to 2^32, candidates further than 32768 back are ignored (encoder.cpp:348) but stay in the table.
+template <bool SAFE, typename TT>
+__device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T, const uint32_t* lcodes,
                                                bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n)
 {
     const int lane = lane_id();
@@ -200,11 +203,13 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         ZZ_T(0);
         // (1) hash, probe + speculative insert; the candidate's bytes are requested at once
         const uint32_t h = calc_hash3((uint32_t)(w >> 8));              // bytes p+1..p+3 (encoder.cpp:344)
-        uint32_t old = 0;
+        uint32_t oldraw = 0;                                            // what the slot held (restored if I am skipped)
         if (active) {
-            old = T[h];                                                 // encoder.cpp:345
-            T[h] = (uint16_t)(p + 1);                                   // encoder.cpp:346
+            oldraw = T[h];                                              // encoder.cpp:345
+            T[h] = (TT)(p + 1);                                         // encoder.cpp:346
         }
+        // the candidate, as pos+1; 0 = none or out of reach (unsigned(distance) <= 32768, encoder.cpp:348)
+        const uint32_t old = (sizeof(TT) == 4 && p + 1 - oldraw > 0x8000u) ? 0 : oldraw;
         uint64_t wc = 0, wc2 = 0;
         if (active && old) ld128<SAFE>(src + (old - 1), end, wc, wc2);  // encoder.cpp:350
         ZZ_WAVE_SYNC();
@@ -217,7 +222,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
 
         ZZ_T(2);
         // (1b) which lanes share a hash inside the group?
-        uint64_t lostmask = ballot(active && rb != ((p + 1) & 0xFFFF));
+        uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1));
         uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
         uint32_t info = 0;
@@ -344,11 +349,11 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
         // highest position wins -- the state the serial loop leaves behind
         const bool is_committed = (committed >> lane) & 1;
         ZZ_WAVE_SYNC();
-        if (active && !is_committed) T[h] = (uint16_t)old;
+        if (active && !is_committed) T[h] = (TT)oldraw;
         if (multimask) {
             ZZ_WAVE_SYNC();
             const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
-            if (winner) T[h] = (uint16_t)(p + 1);
+            if (winner) T[h] = (TT)(p + 1);
         }
         ZZ_WAVE_SYNC();
 
@@ -364,6 +369,11 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, uint16
             }
         }
         cur = next;
+        if (sizeof(TT) == 4 && ring.flushed >= (1u << 24)) {
+            // long streams: slide the ring's origin (by a multiple of the ring size, so slots keep their meaning)
+            const uint32_t kw = ring.flushed & ~(uint32_t)(ZZ_RING_WORDS - 1);
+            ring.out32 += kw; ring.bitpos -= kw * 32; ring.flushed -= kw;
+        }
         ZZ_T(7);
         ZZ_DRAIN();
         w = wnext;
@@ -408,8 +418,8 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
         // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
         ring_append_uniform(ring, (is_final ? 1u : 0u) | (1u << 1), 3);
         // loads may run up to 8 bytes past the packet: only the last two packets can leave the buffer that way
-        if (k + 2 >= P.npk) l1_encode_body<true>(P, T, lcodes, ring, src, end, n);
-        else l1_encode_body<false>(P, T, lcodes, ring, src, end, n);
+        if (k + 2 >= P.npk) l1_encode_body<true, uint16_t>(P, T, lcodes, ring, src, end, n);
+        else l1_encode_body<false, uint16_t>(P, T, lcodes, ring, src, end, n);
         // EOB: codes_f[256] = 7 zero bits (encoder.cpp:371)
         ring_append_uniform(ring, 0, 7);
     }
@@ -429,6 +439,35 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
     if (lane == 0) {
         P.sizes[k] = bytes;
         if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+    }
+}
+
+// The sequential whole-buffer stream of the reference (threaded=false: zzflate.cpp:84-95, one Encoder over the
+// whole input). With a destination of at least zz_bound() bytes level 1 emits ONE fixed-Huffman block for the whole
+// input (encoder.cpp:331-337), which is inherently serial: one wavefront, 32-bit table entries. A compatibility
+// mode, not a throughput mode (use threaded=true for that). Output goes to slot 0; *stream_bytes gets its length.
+__global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P)
+{
+    __shared__ uint32_t T[ZZ_HASH_SIZE];          // absolute position + 1, 0 = empty
+    __shared__ uint32_t ring_words[ZZ_RING_WORDS];
+    __shared__ uint32_t lcodes[ZZ_MAX_LEN + 1];
+    const int lane = lane_id();
+    const uint32_t n = (uint32_t)P.n;
+    {
+        uint4* t4 = (uint4*)T;
+        for (int i = lane; i < (int)(sizeof(T) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
+        for (int l = lane; l <= ZZ_MAX_LEN; l += ZZ_WAVE) lcodes[l] = l >= 3 ? fixed_lcode_packed(l) : 0;
+    }
+    bitring ring;
+    ring_init(ring, ring_words, P.slots);
+    uint32_t* const out0 = ring.out32;
+    ring_append_uniform(ring, 1u | (1u << 1), 3);                      // StartBlock(FixedHuffman, final)
+    if (n) l1_encode_body<true, uint32_t>(P, T, lcodes, ring, P.src, P.src + P.n, n);
+    ring_append_uniform(ring, 0, 7);                                   // codes_f[256]
+    const uint64_t bytes = (uint64_t)(ring.out32 - out0) * 4 + ring_finish(ring);
+    if (lane == 0) {
+        P.sizes[0] = (uint32_t)bytes;                                  // < 4 GiB by the host's size check
+        if (bytes > (uint64_t)P.slot_stride * P.npk) atomicOr(P.err, 1u);
     }
 }
 
