@@ -19,9 +19,9 @@
  * bit-identical to the reference's packet recipe (zzflate.cpp:101-125) wherever that recipe yields a valid
  * DEFLATE encoding, and always valid otherwise. Inputs no longer than one packet therefore produce exactly
  * the reference's single-encoder stream. `threaded == 0` with an input longer than one packet asks for the
- * reference's sequential whole-buffer stream: offered on the device at levels 0 and 1 (bit-identical, level 1
- * on a single wavefront -- a compatibility mode); at levels 2,3 the call fails (error convention below) instead
- * of falling back to a CPU path.
+ * reference's sequential whole-buffer stream: produced on the device too, bit-identical to the reference (given
+ * a destination of at least zz_bound() bytes), but at levels 1..3 by a single wavefront because that stream is
+ * one dependency chain -- a compatibility mode, not a throughput mode. There is no CPU path.
  *
  * Error convention (zzflate.cpp:229-234): *dest_len = ~0 for a bad level or a destination that cannot hold
  * the container header. This library additionally detects a destination that is too small for the stream
@@ -46,7 +46,7 @@ enum {
     ZZ_E_NOSPACE = -2,      /* destination too small */
     ZZ_E_HIP = -3,          /* HIP runtime error / no device */
     ZZ_E_ARG = -4,          /* bad argument (packet size, null pointer) */
-    ZZ_E_UNSUPPORTED = -5   /* sequential whole-buffer mode on more than one packet */
+    ZZ_E_UNSUPPORTED = -5   /* reserved */
 };
 
 #define ZZ_DEFAULT_PACKET 32768u
@@ -86,9 +86,10 @@ int zz_encode_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, ui
                      int format, int level, uint32_t packet_size, void* hip_stream);
 
 /* The reference's sequential whole-buffer stream (threaded == 0, zzflate.cpp:84-95) for device-resident data:
- * level 0 (stored blocks of 65535 bytes, parallel) and level 1 (one fixed-Huffman block for the whole input,
- * produced by a single wavefront: bit-identical to the reference, far slower than packet mode; cap must be at
- * least zz_bound()). n < 2 GiB. Levels 2,3 return ZZ_E_UNSUPPORTED. */
+ * level 0 (stored blocks of 65535 bytes, parallel), level 1 (one fixed-Huffman block for the whole input) and
+ * levels 2,3 (dynamic blocks cut at 20,000 records / 500,000 bytes, hash table carried across blocks), the latter
+ * two produced by a single wavefront: bit-identical to the reference, far slower than packet mode. cap must be
+ * at least zz_bound(); n < 2 GiB (the reference funnels lengths through int). */
 int zz_encode_stream_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                             int format, int level, void* hip_stream);
 

@@ -20,6 +20,7 @@
 #include "zz_level0.h"
 #include "zz_level1.h"
 #include "zz_level2.h"
+#include "zz_stream2.h"
 #include "zz_compact.h"
 #include "zz_datagen.h"
 
@@ -259,8 +260,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
 static int cks_kind_for(int format) { return format == ZZ_ZLIB ? ZZ_CKS_ADLER : format == ZZ_GZIP ? ZZ_CKS_CRC : ZZ_CKS_NONE; }
 
 // The reference's sequential whole-buffer stream (threaded=false, zzflate.cpp:84-95) on the device. Level 0 is
-// parallel (stored blocks of 65535 bytes have known places); level 1 is one fixed-Huffman block produced by a
-// single wavefront (k_stream_l1) -- a compatibility mode, bit-identical to the reference, not a fast one.
+// parallel (stored blocks of 65535 bytes have known places); level 1 is one fixed-Huffman block, levels 2,3 a chain
+// of dynamic blocks, each produced by a single wavefront (k_stream_l1 / k_stream_l2) -- a compatibility mode,
+// bit-identical to the reference, not a fast one.
 static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d_dst, uint64_t cap, int format, int level,
                          hipStream_t st, zz_result* host_res)
 {
@@ -268,11 +270,6 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
     if (!d_dst || (!d_src && n)) { set_err("null buffer"); return ZZ_E_ARG; }
     if (n == 0) return encode_common(c, d_src, 0, 0, true, d_dst, cap, format, cks_kind_for(format), true, level, ZZ_DEFAULT_PACKET, st, host_res);
     if (n >= (1ull << 31)) { set_err("sequential stream: input must be < 2 GiB (the reference funnels lengths through int)"); return ZZ_E_ARG; }
-    if (level >= 2) {
-        set_err("threaded=false (sequential whole-buffer stream) at level >= 2 is only available for inputs of at most one "
-                "packet on the device; use threaded=true");
-        return ZZ_E_UNSUPPORTED;
-    }
     HIPCHK(hipSetDevice(c->device));
     const int hl = header_len(format), tl = trailer_len(format);
     if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
@@ -303,14 +300,15 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
         if (cks_kind != ZZ_CKS_NONE)
             hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk, B, n, cks_kind, c->d_cks_total);
     } else {
-        // one block for the whole input needs bitsAvailable/9 - 8 >= n (encoder.cpp:331-337); a smaller destination
-        // would make the reference cut several blocks, which this mode does not reproduce
+        // level 1: one block for the whole input needs bitsAvailable/9 - 8 >= n (encoder.cpp:331-337); a smaller
+        // destination would make the reference cut several blocks, which this mode does not reproduce
         const uint64_t avail = cap - hl;
-        if (avail < 2 || ((avail - 1) * 8) / 9 < n + 8) {
+        if (level == 1 && (avail < 2 || ((avail - 1) * 8) / 9 < n + 8)) {
             set_err("sequential level-1 stream needs a destination of at least zz_bound() bytes");
             return ZZ_E_NOSPACE;
         }
-        const uint64_t bound = ((uint64_t)9 * n + 17) / 8 + 64;
+        // level >= 2 worst case: every block falls back to stored blocks of <= 65535 bytes
+        const uint64_t bound = level == 1 ? ((uint64_t)9 * n + 17) / 8 + 64 : n + (n / 65535 + 2) * 5 + (n / 400000 + 2) * 8 + 64;
         const uint32_t P = 32768, npk_c = (uint32_t)((n + P - 1) / P);   // checksum chunks
         int rc = ensure_workspace(c, 0, npk_c, 0);
         if (rc) return rc;
@@ -324,8 +322,14 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
         else if (cks_kind == ZZ_CKS_ADLER) hipLaunchKernelGGL(k_adler_packets, dim3(npk_c < 4096 ? npk_c : 4096), dim3(ZZ_WAVE), 0, st, pp);
         zz_packet_params ps = pp;
         ps.npk = 1; ps.slots = c->slots; ps.slot_stride = (uint32_t)bound; ps.cks_kind = ZZ_CKS_NONE;
+        if (level >= 2 && (uint64_t)ZZ_ST_SCRATCH_BYTES > c->l2_scratch_cap) {
+            (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
+            HIPCHK(hipMalloc(&c->l2_scratch, ZZ_ST_SCRATCH_BYTES));
+            c->l2_scratch_cap = ZZ_ST_SCRATCH_BYTES;
+        }
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));
-        hipLaunchKernelGGL(k_stream_l1, dim3(1), dim3(ZZ_WAVE), 0, st, ps);
+        if (level == 1) hipLaunchKernelGGL(k_stream_l1, dim3(1), dim3(ZZ_WAVE), 0, st, ps);
+        else { zz_st_params q; q.pk = ps; q.scratch = c->l2_scratch; hipLaunchKernelGGL(k_stream_l2, dim3(1), dim3(ZZ_WAVE), 0, st, q); }
         if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
         hipLaunchKernelGGL(k_copy_stream, dim3(1024), dim3(256), 0, st, c->slots, c->sizes, d_dst + hl,
                            cap >= (uint64_t)(hl + tl) ? cap - hl - tl : 0, c->d_res);
