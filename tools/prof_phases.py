@@ -38,6 +38,9 @@ if level >= 2:
     print(f"level {level} input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; packets {prof[10]}, tokens/packet {prof[11] / max(1, prof[10]):.0f}, cycles/packet {tot / max(1, prof[10]):.0f} = {tot / max(1, prof[10]) / 32768:.1f} cyc/byte")
     for i, nm in enumerate(names):
         print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
+    pk = max(1, prof[10])
+    print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f" % (
+        prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk))
     sys.exit(0)
 names = ["loop top", "hash+probe issue", "emit prev group", "readback+dup loop", "wait cand load", "info VALU", "walk", "repair+pack", "wait wnext"]
 tot = sum(prof[:9])

@@ -32,7 +32,7 @@ namespace zz {
 
 struct l2_token { uint16_t start, dist, len, pad; };
 #define ZZ_L2_MAX_TOKENS 8192                       // every match covers >= 4 bytes of a <= 32768-byte packet
-#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 8)  // per resident workgroup
+#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 8 + 4096 + 4096)  // per resident workgroup: tokens, covered / match-start bitmaps
 #define ZZ_L2_BLOCKS (ZZ_MAX_PACKET / 64)           // 512 aligned position blocks per packet
 
 // ---- 64-bit fragments through the bit ring ----------------------------------------------------------------
@@ -272,9 +272,11 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
 // of tokens written to `tokens` (ascending start); sets the covered / match-start bitmaps.
 template <bool SAFE>
 __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, uint64_t* mst, l2_token* tokens,
-                                                  const uint8_t* src, const uint8_t* end, uint32_t n, uint64_t before)
+                                                  const uint8_t* src, const uint8_t* end, uint32_t n, uint64_t before,
+                                                  unsigned long long* prof = nullptr)
 {
     const int lane = lane_id();
+    ZZ_PROF_DECL
     const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
     uint32_t ntok = 0;
     uint32_t B = 1;                 // backRefEnd (:380)
@@ -293,6 +295,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
             const uint32_t rest = target - s2;
             batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
         }
+        ZZ_T(6);
         const uint32_t q = base + lane;
         const bool ins = q < n && q != skipPos && q != 0;
         const uint32_t h = calc_hash3(w4);                            // CalcHash(source + j), :388
@@ -319,13 +322,17 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
         ZZ_WAVE_SYNC();
         skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
 
+        ZZ_T(7);
         if (base + 64 > nextProbe && nextProbe < batchEnd) {
             // ---- quick compare info for all 64 probes of this block --------------------------------------
             const bool has = ins && cand1 != 0 && q < batchEnd;
             const uint32_t c = cand1 - 1;
             uint32_t fwd8 = 0, bwd8 = 0, room = 0;
             if (has) {
-                const uint64_t x = ld64<SAFE>(src + q, end) ^ ld64<SAFE>(src + c, end);   // :399
+                uint64_t qa, qb, ca, cbb;                                // 16 bytes at the probe and at the candidate (:399)
+                ld128<SAFE>(src + q, end, qa, qb);
+                ld128<SAFE>(src + c, end, ca, cbb);
+                const uint64_t x = qa ^ ca, x2 = qb ^ cbb;
                 const uint64_t cb = before + c;                        // bytes in front of the candidate
                 room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
                 if (room >= 8) {
@@ -334,13 +341,72 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
                 } else {
                     while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
                 }
-                fwd8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8;
+                fwd8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : (x2 ? 8 + ((uint32_t)__builtin_ctzll(x2) >> 3) : 16);   // 16 = "16 or more"
             }
             const uint32_t broom = bwd8 < room ? bwd8 : room;
+            ZZ_DRAIN();
+            ZZ_T(8);
             // ---- the greedy walk: tokens stay in their probe lane until the block is done ----------------------
+            // Scalar code is slow here (tools/ubench_scalar.hip), so tokens whose lengths are known (< 16 forward,
+            // < 8 backward) are found by a hand-written loop; "8 or more" drops out to the C++ below.
             uint64_t evmask = 0;
             uint32_t tk = 0;            // start | len << 16 of the token found at this lane's probe
+            const uint64_t hasmask = ballot(has);
+            const uint32_t ubase = uniform(base);
             for (;;) {
+                uint32_t np = nextProbe > base ? nextProbe - base : 0;   // first lane that may be probed
+                if (np >= 64) break;
+                uint32_t slow = 0;
+                B = uniform(B); np = uniform(np);   // the compiler does not always see that these are wave-uniform
+                {
+                    uint32_t t1, t2, sf, sb, val, qe;
+                    uint64_t tmp;
+                    int32_t e;
+                    asm volatile(
+                        "1:\n\t"
+                        "v_subrev_u32 %[t1], %[B], %[q]\n\t"          // pend = q - backRefEnd (:404)
+                        "v_min_u32 %[t1], %[t1], %[broom]\n\t"        // backward part that may be used
+                        "v_add_u32 %[t2], %[t1], %[fwd8]\n\t"
+                        "v_cmp_le_u32 vcc, 4, %[t2]\n\t"              // :406-407
+                        "s_lshl_b64 %[tmp], -1, %[np]\n\t"
+                        "s_and_b64 %[tmp], %[tmp], vcc\n\t"
+                        "s_and_b64 %[tmp], %[tmp], %[hasmask]\n\t"
+                        "s_ff1_i32_b64 %[e], %[tmp]\n\t"
+                        "s_cmp_lt_i32 %[e], 0\n\t"
+                        "s_cbranch_scc1 3f\n\t"                       // no further token in this block
+                        "v_readlane_b32 %[sf], %[fwd8], %[e]\n\t"
+                        "v_readlane_b32 %[sb], %[t1], %[e]\n\t"
+                        "s_cmp_eq_u32 %[sf], 16\n\t"
+                        "s_cbranch_scc1 2f\n\t"                       // forward "16 or more": extend in C++
+                        "s_cmp_eq_u32 %[sb], 8\n\t"
+                        "s_cbranch_scc1 2f\n\t"                       // backward "8 or more"
+                        "s_add_u32 %[val], %[sf], %[sb]\n\t"          // match length (:406), <= 22
+                        "s_add_u32 %[qe], %[base], %[e]\n\t"
+                        "s_sub_u32 %[qe], %[qe], %[sb]\n\t"           // match start (:416)
+                        "s_add_u32 %[B], %[qe], %[val]\n\t"           // backRefEnd (:422)
+                        "s_lshl_b32 %[val], %[val], 16\n\t"
+                        "s_or_b32 %[val], %[val], %[qe]\n\t"
+                        "v_mov_b32 %[t2], %[val]\n\t"
+                        "v_cmp_eq_u32 vcc, %[e], %[lanev]\n\t"
+                        "v_cndmask_b32 %[tk], %[tk], %[t2], vcc\n\t"  // the token stays in its probe lane (:420)
+                        "s_bitset1_b64 %[ev], %[e]\n\t"
+                        "s_add_u32 %[np], %[B], 1\n\t"                // j = backRefEnd + 1 (:424)
+                        "s_sub_u32 %[np], %[np], %[base]\n\t"
+                        "s_cmp_lt_u32 %[np], 64\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_branch 3f\n"
+                        "2:\n\t"
+                        "s_mov_b32 %[slow], 1\n"
+                        "3:\n\t"
+                        : [B] "+s"(B), [np] "+s"(np), [ev] "+s"(evmask), [tk] "+v"(tk), [slow] "+s"(slow), [t1] "=&v"(t1),
+                          [t2] "=&v"(t2), [sf] "=&s"(sf), [sb] "=&s"(sb), [val] "=&s"(val), [qe] "=&s"(qe), [tmp] "=&s"(tmp),
+                          [e] "=&s"(e)
+                        : [q] "v"(q), [broom] "v"(broom), [fwd8] "v"(fwd8), [hasmask] "s"(hasmask), [base] "s"(ubase), [lanev] "v"((uint32_t)lane)
+                        : "vcc", "scc");
+                }
+                nextProbe = base + np;
+                if (!slow) break;
+                // one token with a length of "8 or more"
                 const uint32_t pend = q - B;                            // j - backRefEnd (:404)
                 const uint32_t bq = broom < pend ? broom : pend;
                 const uint64_t m = ballot(has && q >= nextProbe && fwd8 + bq >= 4);   // :406-407
@@ -349,9 +415,9 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
                 const uint32_t qe = base + (uint32_t)e;
                 uint32_t fwd = readlane(fwd8, e);
                 uint32_t bw = readlane(bq, e);
-                if (fwd == 8 || bw == 8) {                              // rare: a length is "8 or more"
+                {
                     const uint32_t ce = readlane(c, e);
-                    if (fwd == 8) fwd = wave_extend_match<SAFE>(src, qe, ce, ZZ_MAX_LEN, end);    // remain(), :64-90
+                    if (fwd == 16) fwd = wave_extend_match<SAFE>(src, qe, ce, ZZ_MAX_LEN, end, 16);    // remain(), :64-90
                     const uint32_t re = readlane(room, e), pe = qe - B;
                     const uint32_t blim = re < pe ? re : pe;
                     if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
@@ -365,6 +431,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
                 nextProbe = B + 1;                                                                  // :424
                 if (nextProbe >= base + 64) break;
             }
+            ZZ_T(9);
             // ---- publish this block's tokens and their bitmap bits, all event lanes at once ----------------
             if (evmask) {
                 const bool ev = (evmask >> lane) & 1;
@@ -384,8 +451,12 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
                 ntok += (uint32_t)__builtin_popcountll(evmask);
             }
         }
+        ZZ_T(12);
         w4 = w4next;
     }
+#ifdef ZZ_PROF
+    if (lane == 0 && prof) { for (int _i = 6; _i < 10; ++_i) atomicAdd(&prof[_i], prof_acc[_i]); atomicAdd(&prof[12], prof_acc[12]); }
+#endif
     return ntok;
 }
 
@@ -394,24 +465,21 @@ struct zz_l2_params {
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
 };
 
-#define ZZ_L2_LDS_BYTES (16384 + 4096 + 4096 + 1040 + 1280 + 128 + 80 + 512 + 1152 + 256)
+#define ZZ_L2_LDS_BYTES (16384 + 1280 + 128 + 80 + 512 + 1152 + 256)
 
 __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
-    // ---- LDS carve-up --------------------------------------------------------------------------------------
+    // ---- LDS carve-up (19.3 KiB => 8 workgroups per CU; the status bitmaps live in global scratch) -----------
     __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES];
     uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table; Huffman scratch afterwards
-    uint64_t* cov = (uint64_t*)(lds + 16384);                     // 4096: position covered by a match
-    uint64_t* mst = (uint64_t*)(lds + 16384 + 4096);              // 4096: position starts a match
-    uint16_t* mcount = (uint16_t*)(lds + 24576);                  // 1040: matches before block b (exclusive scan)
-    uint32_t* symF = (uint32_t*)(lds + 24576 + 1040);             // 1280: 286 lit/len + pad | 30 dist at [288..318)
+    uint32_t* symF = (uint32_t*)(lds + 16384);                    // 1280: 286 lit/len + pad | 30 dist at [288..318)
     uint32_t* distF = symF + 288;
-    uint32_t* dcodes = (uint32_t*)(lds + 24576 + 1040 + 1280);    // 128: 30 distance codes
-    uint32_t* metaF = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128);   // 80: 19 meta frequencies
-    uint32_t* ring_words = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128 + 80);   // 512
-    uint32_t* codes = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128 + 80 + 512);  // 1152: 286 lit/len codes
-    uint32_t* misc = (uint32_t*)(lds + 24576 + 1040 + 1280 + 128 + 80 + 512 + 1152);   // 256: lane-0 results [0..3], code-generation work area [16..48)
+    uint32_t* dcodes = (uint32_t*)(lds + 16384 + 1280);           // 128: 30 distance codes
+    uint32_t* metaF = (uint32_t*)(lds + 16384 + 1280 + 128);      // 80: 19 meta frequencies
+    uint32_t* ring_words = (uint32_t*)(lds + 16384 + 1280 + 128 + 80);          // 512
+    uint32_t* codes = (uint32_t*)(lds + 16384 + 1280 + 128 + 80 + 512);         // 1152: 286 lit/len codes
+    uint32_t* misc = (uint32_t*)(lds + 16384 + 1280 + 128 + 80 + 512 + 1152);   // 256: lane-0 results [0..3], code-generation work area [16..48)
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -427,7 +495,10 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
 
     const int lane = lane_id();
     ZZ_PROF_DECL
-    l2_token* tokens = (l2_token*)(Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES);
+    uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES;
+    l2_token* tokens = (l2_token*)my_scratch;
+    uint64_t* cov = (uint64_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 8);            // 4096: position covered by a match
+    uint64_t* mst = cov + 512;                                                 // 4096: position starts a match
 
     for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
         const uint64_t off = (uint64_t)k * P.packet_size;
@@ -442,7 +513,10 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
         __syncthreads();
         {
             uint4* z = (uint4*)lds;
-            for (int i = lane; i < (16384 + 8192) / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T, cov, mst
+            for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
+            uint4* zb = (uint4*)cov;
+            for (int i = lane; i < 8192 / 16; i += ZZ_WAVE) zb[i] = make_uint4(0, 0, 0, 0);   // cov, mst (global)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the zeros reach L2 before the token pass's atomics
             for (int i = lane; i < 320; i += ZZ_WAVE) symF[i] = 0;
             if (lane < 20) metaF[lane] = 0;
         }
@@ -458,50 +532,57 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-440) ===========================================
             // loads may run a few bytes past the packet: only the last two packets can leave the buffer that way
-            const uint32_t ntok = k + 2 >= P.npk ? l2_token_pass<true>(T, cov, mst, tokens, src, end, n, before)
-                                                 : l2_token_pass<false>(T, cov, mst, tokens, src, end, n, before);
+            const uint32_t ntok = k + 2 >= P.npk ? l2_token_pass<true>(T, cov, mst, tokens, src, end, n, before, P.prof)
+                                                 : l2_token_pass<false>(T, cov, mst, tokens, src, end, n, before, P.prof);
             __syncthreads();   // token stores (global) are read back by other lanes below
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // bitmap words were built by L2 atomics: drop stale L1 lines
 
             ZZ_T(1); ZZ_C(10, 1); ZZ_C(11, ntok);
             // ================= histograms (encoder.cpp:442-471) ===============================================
             const uint32_t nblk = (n + 63) >> 6;
-            {   // exclusive scan of per-block match counts
+            // 64 position blocks at a time: lane l holds block b0+l's bitmap words and its exclusive match count
+            // (a wave scan), the inner loops read them back with v_readlane -- no per-block memory access
+            {
                 uint32_t carry = 0;
                 for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
-                    const uint32_t b = b0 + lane;
-                    const uint32_t cnt = b < nblk ? (uint32_t)__builtin_popcountll(mst[b]) : 0;
+                    const uint32_t bl = b0 + lane;
+                    const uint64_t covv = bl < nblk ? cov[bl] : 0, mstv = bl < nblk ? mst[bl] : 0;
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mstv);
                     const uint32_t incl = wave_scan_incl(cnt);
-                    if (b < nblk) mcount[b] = (uint16_t)(carry + incl - cnt);
+                    const uint32_t mcv = carry + incl - cnt;
                     carry += readlane(incl, 63);
-                }
-            }
-            __syncthreads();
-            for (uint32_t b0 = 0; b0 < nblk; b0 += 4) {
-                // four blocks per trip: all loads first, so that their latencies overlap
-                uint32_t byte[4]; uint32_t kind[4]; l2_token tk4[4];
+                    const uint32_t nb_here = nblk - b0 < 64 ? nblk - b0 : 64;
+                    for (uint32_t i0 = 0; i0 < nb_here; i0 += 4) {
+                        // four blocks per trip: all loads first, so that their latencies overlap
+                        uint32_t byte[4]; uint32_t kind[4]; l2_token tk4[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t b = b0 + i;
-                    const uint32_t q = (b << 6) + lane;
-                    kind[i] = 0; byte[i] = 0; tk4[i].start = 0; tk4[i].dist = 1; tk4[i].len = 3; tk4[i].pad = 0;
-                    if (b < nblk && q < n) {
-                        const uint64_t cw = cov[b], mw = mst[b];
-                        if (!((cw >> lane) & 1)) { kind[i] = 1; byte[i] = src[q]; }
-                        else if ((mw >> lane) & 1) {
-                            kind[i] = 2;
-                            tk4[i] = tokens[mcount[b] + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t bi = i0 + i;
+                            const uint32_t q = ((b0 + bi) << 6) + lane;
+                            kind[i] = 0; byte[i] = 0; tk4[i].start = 0; tk4[i].dist = 1; tk4[i].len = 3; tk4[i].pad = 0;
+                            if (bi < nb_here) {
+                                const uint64_t cw = readlane64(covv, (int)bi), mw = readlane64(mstv, (int)bi);
+                                const uint32_t mc = readlane(mcv, (int)bi);
+                                if (q < n) {
+                                    if (!((cw >> lane) & 1)) { kind[i] = 1; byte[i] = src[q]; }
+                                    else if ((mw >> lane) & 1) {
+                                        kind[i] = 2;
+                                        tk4[i] = tokens[mc + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+                                    }
+                                }
+                            }
                         }
-                    }
-                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (kind[i] == 1) atomicAdd(&symF[byte[i]], 1u);
-                    else if (kind[i] == 2) {
-                        uint32_t sym, eb, ev, bucket;
-                        length_symbol(tk4[i].len, sym, eb, ev);
-                        atomicAdd(&symF[sym], 1u);
-                        dist_symbol(tk4[i].dist, bucket, eb, ev);
-                        atomicAdd(&distF[bucket], 1u);
+                        for (int i = 0; i < 4; ++i) {
+                            if (kind[i] == 1) atomicAdd(&symF[byte[i]], 1u);
+                            else if (kind[i] == 2) {
+                                uint32_t sym, eb, ev, bucket;
+                                length_symbol(tk4[i].len, sym, eb, ev);
+                                atomicAdd(&symF[sym], 1u);
+                                dist_symbol(tk4[i].dist, bucket, eb, ev);
+                                atomicAdd(&distF[bucket], 1u);
+                            }
+                        }
                     }
                 }
             }
@@ -592,34 +673,46 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
                 ring_append(ring, bits, nb);
             }
             // body: WriteRecords (:149-169) by position
-            for (uint32_t b = 0; b < nblk; ++b) {
-                const uint64_t cw = cov[b], mw = mst[b];
-                const uint32_t q = (b << 6) + lane;
-                uint64_t bits = 0; uint32_t nb = 0;
-                const uint64_t live = ~cw | mw;                                    // literal or match start
-                if (q < n && ((live >> lane) & 1)) {
-                    if (!((cw >> lane) & 1)) {
-                        const uint32_t cd = codes[src[q]];
-                        bits = cd & 0xFFFF; nb = cd >> 16;
-                    } else {
-                        const l2_token t = tokens[mcount[b] + __builtin_popcountll(mw & ((1ull << lane) - 1))];
-                        uint32_t sym, eb, ev, bucket, deb, dev;
-                        length_symbol(t.len, sym, eb, ev);
-                        const uint32_t lc = codes[sym];
-                        uint32_t ln = lc >> 16;
-                        uint64_t v = (lc & 0xFFFF) | ((uint64_t)ev << ln);          // Merge, :121-124
-                        ln += eb;
-                        dist_symbol(t.dist, bucket, deb, dev);
-                        const uint32_t dc = dcodes[bucket];
-                        v |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
-                        ln += dc >> 16;
-                        v |= (uint64_t)dev << ln;
-                        ln += deb;
-                        bits = v; nb = ln;
+            {
+                uint32_t carry = 0;
+                for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+                    const uint32_t bl = b0 + lane;
+                    const uint64_t covv = bl < nblk ? cov[bl] : 0, mstv = bl < nblk ? mst[bl] : 0;
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mstv);
+                    const uint32_t incl = wave_scan_incl(cnt);
+                    const uint32_t mcv = carry + incl - cnt;
+                    carry += readlane(incl, 63);
+                    const uint32_t nb_here = nblk - b0 < 64 ? nblk - b0 : 64;
+                    for (uint32_t bi = 0; bi < nb_here; ++bi) {
+                        const uint64_t cw = readlane64(covv, (int)bi), mw = readlane64(mstv, (int)bi);
+                        const uint64_t live = ~cw | mw;                            // literal or match start
+                        if (bi + 1 < nb_here && live == 0) continue;               // block wholly inside a match
+                        const uint32_t q = ((b0 + bi) << 6) + lane;
+                        uint64_t bits = 0; uint32_t nb = 0;
+                        if (q < n && ((live >> lane) & 1)) {
+                            if (!((cw >> lane) & 1)) {
+                                const uint32_t cd = codes[src[q]];
+                                bits = cd & 0xFFFF; nb = cd >> 16;
+                            } else {
+                                const l2_token t = tokens[readlane(mcv, (int)bi) + __builtin_popcountll(mw & ((1ull << lane) - 1))];
+                                uint32_t sym, eb, ev, bucket, deb, dev;
+                                length_symbol(t.len, sym, eb, ev);
+                                const uint32_t lc = codes[sym];
+                                uint32_t ln = lc >> 16;
+                                uint64_t v = (lc & 0xFFFF) | ((uint64_t)ev << ln);          // Merge, :121-124
+                                ln += eb;
+                                dist_symbol(t.dist, bucket, deb, dev);
+                                const uint32_t dc = dcodes[bucket];
+                                v |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
+                                ln += dc >> 16;
+                                v |= (uint64_t)dev << ln;
+                                ln += deb;
+                                bits = v; nb = ln;
+                            }
+                        }
+                        ring_append64(ring, bits, nb);
                     }
                 }
-                if (b + 1 < nblk && (live == 0)) continue;                         // block wholly inside a match
-                ring_append64(ring, bits, nb);
             }
             {   // codes[256] (:300)
                 const uint32_t cd = codes[256];
@@ -648,7 +741,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
 
 static inline uint32_t l2_grid(uint32_t npk)
 {
-    const uint32_t resident = 256 * 5;      // CUs x workgroups the LDS budget admits
+    const uint32_t resident = 256 * 8;      // CUs x workgroups the LDS budget admits
     return npk < resident ? npk : resident;
 }
 static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, hipStream_t st)
