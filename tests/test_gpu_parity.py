@@ -123,6 +123,27 @@ def test_sequential_stream_matches_reference_goldens(gpu, oracle, corpus, lvl):
     assert zz.ZzFlateEncode(d, zz.Config(zz.Format.Gzip, lvl, False)) == oracle.encode(d, 1, lvl)
 
 
+def test_randomized_inputs_and_packet_sizes(gpu, oracle):
+    """Seeded fuzz: structured random inputs, random lengths and packet sizes, every level and container."""
+    import random
+    rng = random.Random(20261003)
+    kinds = SYNTH_KINDS + ["longperiod"]
+    for it in range(120):
+        kind = rng.choice(kinds)
+        n = rng.choice([rng.randint(1, 300), rng.randint(300, 40000), rng.randint(40000, 200000)])
+        d = synth(kind, n, 100 + it)
+        if it % 3 == 0:   # splice two kinds: long repeats meeting noise
+            e = synth(rng.choice(kinds), n, 500 + it)
+            cut = rng.randint(0, n)
+            d = d[:cut] + e[cut:]
+        P = rng.choice([32768, 32768, 32768, 16384, 8192, 4096, 1000, 777, rng.randint(1, 32768)])
+        lvl = rng.randint(0, 3)
+        fmt = rng.randint(0, 2)
+        got = gpu.encode(d, fmt, lvl, P)
+        assert got == oracle.encode_packets(d, fmt, lvl, P), (it, kind, n, P, lvl, fmt)
+        assert zlib.decompressobj(WBITS[fmt]).decompress(got) == d
+
+
 def test_empty_input_is_a_valid_stream(gpu):
     """D8: the reference emits no block for empty input (invalid stream); we emit one empty final block."""
     for fmt in range(3):
