@@ -224,26 +224,25 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // (1b) which lanes share a hash inside the group?
         uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1));
         uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
+        uint64_t hardmask = 0;     // ... more than twice
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
-        uint32_t info = 0;
-        while (lostmask) {
-            ZZ_C(15, 1);
+        while (lostmask) {         // one trip per hash value that occurs more than once: keep it lean
             const int l0 = __builtin_ctzll(lostmask);
             const uint32_t hv = readlane(h, l0);
-            const bool mine = active && h == hv;
-            const uint64_t set = ballot(mine);
-            if (mine) {
-                myset = set;
-                const uint64_t below = set & ((1ull << lane) - 1);
-                if (below) {
-                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 10);
-                    if (__builtin_popcountll(set) > 2) info |= ZZ_WI_HARD;
-                }
-            }
+            const uint64_t set = ballot(active && h == hv);
+            if ((set >> lane) & 1) myset = set;
             multimask |= set;
+            if (__builtin_popcountll(set) > 2) hardmask |= set;
             lostmask &= ~set;
         }
-
+        uint32_t info = 0;
+        if (multimask) {
+            const uint64_t below = myset & ((1ull << lane) - 1);          // earlier lanes with my hash
+            if (below) {
+                info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 10);
+                if ((hardmask >> lane) & 1) info |= ZZ_WI_HARD;
+            }
+        }
         ZZ_T(3);
         ZZ_DRAIN();
         ZZ_T(4);
