@@ -230,7 +230,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
             HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
         } else if (level == 1) {
-            hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_WAVE), 0, st, pp);
+            // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
+            static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+            hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_WAVE), pad_lds, st, pp);
         } else {
             launch_level2(pp, c->l2_scratch, st);
         }

@@ -86,6 +86,7 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 #define ZZ_WI_HARD 0x20000u                  // its hash occurs more than twice
 #define ZZ_WI_EXTA 0x40000u                  // lenA is "16 or more" and more bytes remain: extend
 #define ZZ_WI_EXTB 0x80000u
+#define ZZ_WI_NEXT(i) (((i) >> 20) & 127u)   // plain matches: first event lane at or after the match end (64 = none)
 #define ZZ_WI_CAP 16u                        // bytes compared up front (two 8-byte words per lane)
 
 // The inner loop of the walk (encoder.cpp:341-368 replayed over ballot masks), hand-written because scalar code
@@ -111,17 +112,26 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_and_b64 %[tmp], %[tmp], %[E]\n\t"
         "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first event at or after pos (-1: none)
         "s_cmp_lt_i32 %[e], 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
+        "s_cbranch_scc1 3f\n"
+        "9:\n\t"
         "v_readlane_b32 %[inf], %[info], %[e]\n\t"
         "s_and_b32 %[len], %[inf], 0x70000\n\t"     // DUP | HARD | EXTA
         "s_cmp_eq_u32 %[len], 0\n\t"
         "s_cbranch_scc0 4f\n\t"
-        "s_and_b32 %[len], %[inf], 31\n"            // plain match, length lenA (encoder.cpp:350-354)
-        "5:\n\t"
+        "s_and_b32 %[len], %[inf], 31\n\t"          // plain match, length lenA (encoder.cpp:350-354)
         "s_bitset1_b64 %[mst], %[e]\n\t"            // a match starts here (encoder.cpp:356)
         "s_bfm_b64 %[tmp], %[len], %[e]\n\t"        // lanes e .. e+len-1
         "s_or_b64 %[cov], %[cov], %[tmp]\n\t"
         "s_add_u32 %[pos], %[e], %[len]\n\t"        // encoder.cpp:361-362
+        "s_bfe_u32 %[e], %[inf], 0x70014\n\t"       // hop to the next event at or after the match end
+        "s_cmp_lt_u32 %[e], 64\n\t"
+        "s_cbranch_scc1 9b\n\t"
+        "s_branch 3f\n"
+        "5:\n\t"
+        "s_bitset1_b64 %[mst], %[e]\n\t"            // (matches found through the in-group candidate logic)
+        "s_bfm_b64 %[tmp], %[len], %[e]\n\t"
+        "s_or_b64 %[cov], %[cov], %[tmp]\n\t"
+        "s_add_u32 %[pos], %[e], %[len]\n\t"
         "s_cmp_lt_u32 %[pos], 64\n\t"
         "s_cbranch_scc1 1b\n\t"
         "s_branch 3f\n"
@@ -169,7 +179,7 @@ __device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lc
     uint32_t bits = 0, nb = 0;
     if (tok & ZZ_TOK_MATCH) {
         const uint32_t tlen = (tok >> 16) & 0x1FF, tdist = tok & 0xFFFF;
-        const uint32_t lc = lcodes[tlen];                                // lcodes_f[matchLength], encoder.cpp:358
+        const uint32_t lc = lcodes[tlen - 3];                            // lcodes_f[matchLength], encoder.cpp:358
         const uint32_t ll = lc >> 16;
         uint32_t bucket, eb, ev;
         dist_symbol(tdist, bucket, eb, ev);                              // WriteDistance, encoder.cpp:135-141
@@ -274,6 +284,13 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
         const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
+        // a plain match knows where the walk continues: the first event at or after its end (64 = none). With that
+        // in the info word the scalar loop hops from match to match without re-scanning the event mask.
+        {
+            const uint32_t endl = (uint32_t)lane + la;
+            const uint64_t m = endl >= 64 ? 0 : (E & (~0ull << endl));
+            info |= (m ? (uint32_t)__builtin_ctzll(m) : 64u) << 20;
+        }
 
         ZZ_T(5); ZZ_C(10, 1);
         // (3) the walk: replays the reference's decisions in order (encoder.cpp:341-368). Scalar code is slow
@@ -387,7 +404,9 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
 {
     __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
-    __shared__ uint32_t lcodes[ZZ_MAX_LEN + 1];   // lcodes_f (fixedhuffmanluts.cpp:8-46), packed
+    // lcodes_f (fixedhuffmanluts.cpp:8-46), packed, indexed by length - 3. 256 entries, not 259: table + ring + this is
+    // then exactly 17,920 bytes = 35 LDS granules, which lets NINE workgroups share a CU instead of eight.
+    __shared__ uint32_t lcodes[ZZ_MAX_LEN - 2];
 
     const int lane = lane_id();
     const uint32_t k = blockIdx.x;
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l1(zz_packet_params P)
     {
         uint4* t4 = (uint4*)T;
         for (int i = lane; i < (int)(sizeof(T) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
-        for (int l = lane; l <= ZZ_MAX_LEN; l += ZZ_WAVE) lcodes[l] = l >= 3 ? fixed_lcode_packed(l) : 0;
+        for (int l = lane; l < ZZ_MAX_LEN - 2; l += ZZ_WAVE) lcodes[l] = fixed_lcode_packed(l + 3);
     }
     bitring ring;
     ring_init(ring, ring_words, out);   // includes the fence that publishes T and lcodes
@@ -449,13 +468,13 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P)
 {
     __shared__ uint32_t T[ZZ_HASH_SIZE];          // absolute position + 1, 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
-    __shared__ uint32_t lcodes[ZZ_MAX_LEN + 1];
+    __shared__ uint32_t lcodes[ZZ_MAX_LEN - 2];
     const int lane = lane_id();
     const uint32_t n = (uint32_t)P.n;
     {
         uint4* t4 = (uint4*)T;
         for (int i = lane; i < (int)(sizeof(T) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
-        for (int l = lane; l <= ZZ_MAX_LEN; l += ZZ_WAVE) lcodes[l] = l >= 3 ? fixed_lcode_packed(l) : 0;
+        for (int l = lane; l < ZZ_MAX_LEN - 2; l += ZZ_WAVE) lcodes[l] = fixed_lcode_packed(l + 3);
     }
     bitring ring;
     ring_init(ring, ring_words, P.slots);
