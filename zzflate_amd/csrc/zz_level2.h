@@ -465,21 +465,23 @@ struct zz_l2_params {
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
 };
 
-#define ZZ_L2_LDS_BYTES (16384 + 1280 + 128 + 80 + 512 + 1152 + 256)
+#define ZZ_L2_LDS_BYTES (16384 + 512 + 256)
 
-__global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
+__global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
-    // ---- LDS carve-up (19.3 KiB => 8 workgroups per CU; the status bitmaps live in global scratch) -----------
+    // ---- LDS carve-up: 17,152 bytes => nine workgroups per CU (with <= 168 VGPRs: three waves per SIMD). The hash
+    // table is dead once the token pass is over, so histograms, Huffman scratch and code tables all live inside it;
+    // the status bitmaps live in global scratch.
     __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES];
-    uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table; Huffman scratch afterwards
-    uint32_t* symF = (uint32_t*)(lds + 16384);                    // 1280: 286 lit/len + pad | 30 dist at [288..318)
+    uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table during the token pass
+    uint32_t* symF = (uint32_t*)(lds + 8192);                     // 1280: 286 lit/len + pad | 30 dist at [288..318)
     uint32_t* distF = symF + 288;
-    uint32_t* dcodes = (uint32_t*)(lds + 16384 + 1280);           // 128: 30 distance codes
-    uint32_t* metaF = (uint32_t*)(lds + 16384 + 1280 + 128);      // 80: 19 meta frequencies
-    uint32_t* ring_words = (uint32_t*)(lds + 16384 + 1280 + 128 + 80);          // 512
-    uint32_t* codes = (uint32_t*)(lds + 16384 + 1280 + 128 + 80 + 512);         // 1152: 286 lit/len codes
-    uint32_t* misc = (uint32_t*)(lds + 16384 + 1280 + 128 + 80 + 512 + 1152);   // 256: lane-0 results [0..3], code-generation work area [16..48)
+    uint32_t* codes = (uint32_t*)(lds + 8192 + 1280);             // 1152: 286 lit/len codes
+    uint32_t* dcodes = (uint32_t*)(lds + 8192 + 1280 + 1152);     // 128: 30 distance codes
+    uint32_t* metaF = (uint32_t*)(lds + 8192 + 1280 + 1152 + 128);            // 80: 19 meta frequencies
+    uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512
+    uint32_t* misc = (uint32_t*)(lds + 16384 + 512);              // 256: lane-0 results [0..3], code-generation work area [16..48)
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -517,8 +519,6 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
             uint4* zb = (uint4*)cov;
             for (int i = lane; i < 8192 / 16; i += ZZ_WAVE) zb[i] = make_uint4(0, 0, 0, 0);   // cov, mst (global)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the zeros reach L2 before the token pass's atomics
-            for (int i = lane; i < 320; i += ZZ_WAVE) symF[i] = 0;
-            if (lane < 20) metaF[lane] = 0;
         }
         bitring ring;
         ring_init(ring, ring_words, out);
@@ -536,6 +536,9 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
                                                  : l2_token_pass<false>(T, cov, mst, tokens, src, end, n, before, P.prof);
             __syncthreads();   // token stores (global) are read back by other lanes below
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // bitmap words were built by L2 atomics: drop stale L1 lines
+            for (int i = lane; i < 320; i += ZZ_WAVE) symF[i] = 0;   // the hash table is dead now: its space is reused
+            if (lane < 20) metaF[lane] = 0;
+            __syncthreads();
 
             ZZ_T(1); ZZ_C(10, 1); ZZ_C(11, ntok);
             // ================= histograms (encoder.cpp:442-471) ===============================================
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_encode_l2(zz_l2_params Q)
 
 static inline uint32_t l2_grid(uint32_t npk)
 {
-    const uint32_t resident = 256 * 8;      // CUs x workgroups the LDS budget admits
+    const uint32_t resident = 256 * 9;      // CUs x workgroups the LDS budget admits
     return npk < resident ? npk : resident;
 }
 static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, hipStream_t st)
