@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--gen", default="text", choices=list(GEN))
     ap.add_argument("--format", default="zlib", choices=["zlib", "gzip", "deflate"])
     ap.add_argument("--packet", type=int, default=32768)
+    ap.add_argument("--chunks", type=int, default=4, help="N > 1: pieces per shard; piece c travels to rank 0 "
+                    "while piece c+1 is encoded (1 = one gather after the whole shard)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
@@ -146,6 +148,12 @@ def main():
     shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
     xdev = "cuda" if backend == "nccl" else "cpu"     # where the exchange buffers live
     gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (world > 1 and rank == 0) else None
+    C = max(1, args.chunks) if world > 1 else 1
+    assert n % (C * P) == 0, "--mib must split into --chunks packet-aligned pieces"
+    pipe = None
+    if world > 1 and C > 1:
+        from zzflate_amd import sharded
+        pipe = sharded.PipelinedGather(dist, fmt, cap, torch.device(xdev))
     torch.cuda.synchronize()
 
     kernel_ms = []
@@ -156,7 +164,7 @@ def main():
             w = ctx.encode(src, n, shard, cap, fmt, args.level, P)
             state["out_bytes"] = w
             state["comp_bytes"] = w
-        else:
+        elif pipe is None:
             from zzflate_amd import sharded
             w, cks = ctx.encode_shard(src, n, shard, cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
                                       level=args.level, packet_size=P)
@@ -166,6 +174,25 @@ def main():
             if rank == 0:
                 state["out_bytes"] = tot
             state["comp_bytes"] = w
+        else:
+            # the shard in C pieces: piece c is on its way to rank 0 (async grouped send/recv) while c+1 is encoded
+            pipe.begin()
+            pn, wsum, kms, off = n // C, 0, 0.0, 0
+            for c in range(C):
+                piece = shard[off:]
+                w, cks = ctx.encode_shard(src[c * pn:], pn, piece, cap - off, halo=halo + c * pn,
+                                          is_last=(rank == world - 1 and c == C - 1), checksum=fmt,
+                                          level=args.level, packet_size=P)
+                kms += ctx.last_kernel_ms()
+                pipe.push(piece if backend == "nccl" else piece[:w].cpu(), w, cks, pn)
+                off += (w + 255) & ~255
+                wsum += w
+            tot = pipe.finish(gathered)
+            if rank == 0:
+                state["out_bytes"] = tot
+            state["comp_bytes"] = wsum
+            kernel_ms.append(kms)
+            return
         kernel_ms.append(ctx.last_kernel_ms())
 
     def barrier():
@@ -256,7 +283,7 @@ def main():
             "config": {
                 "workload": f"{args.mib} MiB synthetic {args.gen} per GPU (zz_generate_device kind={args.gen}, seed "
                             f"{SEEDS[args.gen]:#x}), level {args.level}, {args.format} container, {P}-byte packets, "
-                            f"input and output resident in HBM" + (", shards gathered to rank 0 over RCCL" if world > 1 else ""),
+                            f"input and output resident in HBM" + (f", shards gathered to rank 0 over RCCL in {C} overlapped piece(s)" if world > 1 else ""),
                 "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format,
             },
             "roofline": {

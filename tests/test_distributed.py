@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fname, fmt, lvl, P, result_path):
+def _worker(rank, world, port, fname, fmt, lvl, P, result_path, chunks=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -44,9 +44,22 @@ def _worker(rank, world, port, fname, fmt, lvl, P, result_path):
         out += oracle.packet(data, lvl, k * P, ln, k == npk_total - 1)
     part = data[off:off + n]
     cks = zz.adler32x(0, part) if fmt == 0 else (zz.crc32(part) if fmt == 1 else 0)
-    shard = torch.frombuffer(bytearray(out) if out else bytearray(1), dtype=torch.uint8)
     outbuf = torch.zeros(2 * len(data) + 4096, dtype=torch.uint8) if rank == 0 else None
-    total = sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf)
+    if chunks <= 1:
+        shard = torch.frombuffer(bytearray(out) if out else bytearray(1), dtype=torch.uint8)
+        total = sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf)
+    else:
+        # pipelined variant: the shard leaves in `chunks` packet-aligned pieces
+        pg = sharded.PipelinedGather(dist, fmt, 2 * len(data) + 4096, torch.device("cpu"))
+        pk_lo, pk_hi = off // P, (off + n + P - 1) // P
+        per = (pk_hi - pk_lo + chunks - 1) // chunks
+        for c in range(chunks):
+            a, b = min(pk_lo + c * per, pk_hi), min(pk_lo + (c + 1) * per, pk_hi)
+            piece = b"".join(oracle.packet(data, lvl, k * P, min(P, len(data) - k * P), k == npk_total - 1) for k in range(a, b))
+            pin = data[a * P: min(b * P, len(data))] if b > a else b""
+            pc = zz.adler32x(0, pin) if fmt == 0 else (zz.crc32(pin) if fmt == 1 else 0)
+            pg.push(torch.frombuffer(bytearray(piece) if piece else bytearray(1), dtype=torch.uint8), len(piece), pc, len(pin))
+        total = pg.finish(outbuf)
     if rank == 0:
         got = outbuf[:total].numpy().tobytes()
         want = oracle.encode_packets(data, fmt, lvl, P)
@@ -61,6 +74,15 @@ def test_two_rank_gather_equals_single_stream(tmp_path, fmt, lvl, P):
     fname = os.path.join(ROOT, "tests", "golden", "corpus", "alice29.txt")
     res = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), fname, fmt, lvl, P, res), nprocs=2, join=True)
+    assert open(res).read() == "ok"
+
+
+@pytest.mark.parametrize("fmt,lvl,P,chunks", [(0, 1, 4096, 4), (1, 2, 8192, 3), (0, 2, 32768, 2)])
+def test_two_rank_pipelined_gather(tmp_path, fmt, lvl, P, chunks):
+    """The overlapped exchange (pieces sent while the next piece is encoded) assembles the same stream."""
+    fname = os.path.join(ROOT, "tests", "golden", "corpus", "lcet10.txt")
+    res = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), fname, fmt, lvl, P, res, chunks), nprocs=2, join=True)
     assert open(res).read() == "ok"
 
 

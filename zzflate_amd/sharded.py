@@ -77,3 +77,72 @@ def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None
     if tail:
         out[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
     return off + len(tail)
+
+
+class PipelinedGather:
+    """The same join with the transfer hidden behind the encoding ("overlap by gathering ... as shards
+    finish"). Every rank encodes its shard in a few packet-aligned pieces; after each piece the (bytes, checksum,
+    input bytes) triples are all-gathered and the piece leaves for rank 0 as an asynchronous grouped send/recv
+    while the next piece is being encoded. Pieces land in a per-rank staging region on rank 0 (their final offsets
+    depend on sizes not known yet); `finish` waits for the transfers and assembles header + shards + trailer with
+    device-to-device copies. All ranks must call `push` the same number of times per stream.
+    """
+
+    def __init__(self, dist, fmt, cap_per_rank, device, group=None):
+        self.dist, self.fmt, self.group = dist, int(fmt), group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.cap = cap_per_rank
+        self.device = device
+        self.staging = torch.empty(cap_per_rank * self.world, dtype=torch.uint8, device=device) if self.rank == 0 else None
+        self.begin()
+
+    def begin(self):
+        self.reqs = []
+        self.fill = [0] * self.world          # bytes received so far per rank (rank 0's view; same on every rank)
+        self.parts = [[] for _ in range(self.world)]   # per rank: [(checksum partial, input bytes)] in piece order
+        self.keep = []                        # tensors that must outlive their sends
+
+    def push(self, piece, nbytes, cks, n_in):
+        dist, dev = self.dist, self.device
+        meta = torch.tensor([nbytes, cks, n_in], dtype=torch.int64, device=dev)
+        metas = torch.empty(3 * self.world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(metas, meta, group=self.group)
+        m = metas.cpu().tolist()
+        sizes, ckss, lens = m[0::3], m[1::3], m[2::3]
+        ops = []
+        for r in range(self.world):
+            if sizes[r] > self.cap - self.fill[r]:
+                raise RuntimeError("staging region too small")
+            if self.rank == 0:
+                dst = self.staging[r * self.cap + self.fill[r]: r * self.cap + self.fill[r] + sizes[r]]
+                if r == 0:
+                    dst.copy_(piece[:sizes[0]])
+                elif sizes[r]:
+                    ops.append(dist.P2POp(dist.irecv, dst, r, self.group))
+            elif r == self.rank and sizes[r]:
+                ops.append(dist.P2POp(dist.isend, piece[:sizes[r]], 0, self.group))
+                self.keep.append(piece)
+            self.fill[r] += sizes[r]
+            self.parts[r].append((ckss[r], lens[r]))
+        if ops:
+            self.reqs.extend(dist.batch_isend_irecv(ops))
+
+    def finish(self, out=None):
+        for req in self.reqs:
+            req.wait()
+        self.keep = []
+        if self.rank != 0:
+            return None
+        head = header(self.fmt)
+        off = len(head)
+        assert out is not None and out.numel() >= off + sum(self.fill) + 8
+        for r in range(self.world):
+            out[off: off + self.fill[r]].copy_(self.staging[r * self.cap: r * self.cap + self.fill[r]])
+            off += self.fill[r]
+        flat = [p for r in range(self.world) for p in self.parts[r]]
+        tail = trailer(self.fmt, combine_checksums(self.fmt, flat), sum(n for _, n in flat))
+        if head:
+            out[:len(head)].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
+        if tail:
+            out[off: off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
+        return off + len(tail)
