@@ -33,14 +33,14 @@ for it in range(2):
     prof = (ctypes.c_ulonglong * 16)()
     L.zz_debug_read_prof(h, prof)
 if level >= 2:
-    names = ["init+adler", "token pass", "histograms", "huffman (lane 0)", "codes (lane 0)", "emit"]
+    names = ["init+adler", "token pass", "counter unpack", "huffman (lane 0)", "codes (lane 0)", "emit"]
     tot = sum(prof[:6])
     print(f"level {level} input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; packets {prof[10]}, tokens/packet {prof[11] / max(1, prof[10]):.0f}, cycles/packet {tot / max(1, prof[10]):.0f} = {tot / max(1, prof[10]) / 32768:.1f} cyc/byte")
     for i, nm in enumerate(names):
         print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
     pk = max(1, prof[10])
-    print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f" % (
-        prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk))
+    print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f | finish block %.0f" % (
+        prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[13] / pk))
     sys.exit(0)
 names = ["loop top", "hash+probe issue", "emit prev group", "readback+dup loop", "wait cand load", "info VALU", "walk", "repair+pack", "wait wnext"]
 tot = sum(prof[:9])

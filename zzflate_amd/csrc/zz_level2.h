@@ -14,8 +14,13 @@
 //                literal count) are measured by the whole wave, 4 bytes per lane, for the chosen probe only.
 //                The two positions the reference never inserts (packet byte 0 and the first byte of a batch
 //                that the previous batch did not overrun, encoder.cpp:383,435-436) are skipped.
-//   histograms   GetFrequencies (encoder.cpp:442-471): per-position status bitmaps (covered / match start)
-//                make this and the emission pass parallel over positions; counts via LDS atomics.
+//   records      The parse is final 320 positions behind the probe front (a later match can extend backward over at
+//                most 258 pending literals), so the token pass itself turns finished 64-position blocks into the
+//                reference's record sequence (literal | match, encoder.cpp:420,428-431): covered / match-start
+//                bits sit in a 16-word LDS window, live positions are compacted to a dense u16 record array.
+//   histograms   GetFrequencies (encoder.cpp:442-471) falls out of the same pass: literals are counted when their
+//                block is finished, length / distance symbols when a match is published (LDS atomics on packed
+//                16-bit counters -- a packet has fewer than 32768 records).
 //   code build   CalcLengths (huffman.cpp:122-154): heap Huffman + frequency-floor length limit. Code lengths
 //                depend on libstdc++'s make_heap/pop_heap/push_heap element movements (ties!), so lane 0
 //                replays bits/stl_heap.h (GCC 11: __push_heap :134-148, __adjust_heap :223-248) on LDS arrays.
@@ -30,10 +35,38 @@
 
 namespace zz {
 
-struct l2_token { uint16_t start, dist, len, pad; };
 #define ZZ_L2_MAX_TOKENS 8192                       // every match covers >= 4 bytes of a <= 32768-byte packet
-#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 8 + 4096 + 4096)  // per resident workgroup: tokens, covered / match-start bitmaps
-#define ZZ_L2_BLOCKS (ZZ_MAX_PACKET / 64)           // 512 aligned position blocks per packet
+// per resident workgroup: matches as len << 16 | dist (u32), records as u16 (literal byte | ZZ_L2_REC_MATCH)
+#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 4 + ZZ_MAX_PACKET * 2)
+#define ZZ_L2_REC_MATCH 0x100u
+#define ZZ_L2_REC_NONE 0x200u
+#define ZZ_L2_WIN 16                                // bitmap window, words of 64 positions (11 are live at a time)
+#define ZZ_L2_LAG 5                                 // a block is final once the probe front is 5 blocks ahead
+#define ZZ_L2_HIST_WORDS 160                        // 286 lit/len + 30 distance counters, two per word
+
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m)   // set bits of m below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ void hist_add(uint32_t* histP, uint32_t idx) { atomicAdd(&histP[idx >> 1], 1u << ((idx & 1) << 4)); }
+
+// One finished block of 64 positions -> records + literal counts; frees its window slot. `byte` = src[64F + lane].
+__device__ __forceinline__ uint32_t l2_finish_block(uint64_t* covw, uint64_t* mstw, uint32_t* histP, uint16_t* recs,
+                                                    uint32_t nrec, uint32_t F, uint32_t n, uint32_t byte)
+{
+    const int lane = lane_id();
+    const uint32_t s = F & (ZZ_L2_WIN - 1);
+    const uint64_t cw = covw[s], mw = mstw[s];
+    ZZ_WAVE_SYNC();
+    if (lane == 0) { covw[s] = 0; mstw[s] = 0; }
+    const uint32_t p = (F << 6) + (uint32_t)lane;
+    const bool lit = p < n && !((cw >> lane) & 1);
+    const bool ms = p < n && ((mw >> lane) & 1);
+    const uint64_t live = ballot(lit || ms);
+    if (lit) hist_add(histP, byte);
+    if (lit || ms) recs[nrec + mbcnt(live)] = (uint16_t)(ms ? ZZ_L2_REC_MATCH : byte);
+    return nrec + (uint32_t)__builtin_popcountll(live);
+}
 
 // ---- 64-bit fragments through the bit ring ----------------------------------------------------------------
 __device__ __forceinline__ void ring_flush_all_full(bitring& r)
@@ -269,14 +302,16 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
 
 // ---- token pass ------------------------------------------------------------------------------------------------
 // FirstPass + AddHashEntries over the whole packet (encoder.cpp:217-248, 375-440, 474-480). Returns the number
-// of tokens written to `tokens` (ascending start); sets the covered / match-start bitmaps.
+// of matches written to `tokens` (ascending start) and, through nrec_out, the number of records in `recs`.
 template <bool SAFE>
-__device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, uint64_t* mst, l2_token* tokens,
-                                                  const uint8_t* src, const uint8_t* end, uint32_t n, uint64_t before,
+__device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
+                                                  uint32_t* tokens, uint16_t* recs, const uint8_t* src,
+                                                  const uint8_t* end, uint32_t n, uint64_t before, uint32_t& nrec_out,
                                                   unsigned long long* prof = nullptr)
 {
     const int lane = lane_id();
     ZZ_PROF_DECL
+    uint32_t nrec = 0, Fnext = 0;
     const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
     uint32_t ntok = 0;
     uint32_t B = 1;                 // backRefEnd (:380)
@@ -297,6 +332,9 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
         }
         ZZ_T(6);
         const uint32_t q = base + lane;
+        // the block that becomes final in this trip: its bytes are fetched now, used at the bottom
+        uint32_t fbyte = 0;
+        if (base >= 64 * ZZ_L2_LAG) fbyte = src[q - 64 * ZZ_L2_LAG];
         const bool ins = q < n && q != skipPos && q != 0;
         const uint32_t h = calc_hash3(w4);                            // CalcHash(source + j), :388
         uint32_t old = 0;
@@ -436,26 +474,44 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* cov, ui
             if (evmask) {
                 const bool ev = (evmask >> lane) & 1;
                 if (ev) {
-                    const uint32_t ms = tk & 0xFFFF, mlen = tk >> 16;
-                    l2_token t; t.start = (uint16_t)ms; t.dist = (uint16_t)(q - c); t.len = (uint16_t)mlen; t.pad = 0;
-                    tokens[ntok + (uint32_t)__builtin_popcountll(evmask & ((1ull << lane) - 1))] = t;
+                    const uint32_t ms = tk & 0xFFFF, mlen = tk >> 16, dist = q - c;
+                    tokens[ntok + mbcnt(evmask)] = (mlen << 16) | dist;
+                    // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
                     const uint32_t last = ms + mlen - 1;
                     for (uint32_t wi = ms >> 6; wi <= (last >> 6); ++wi) {
                         const uint32_t lo = wi == (ms >> 6) ? (ms & 63) : 0;
                         const uint32_t hi = wi == (last >> 6) ? (last & 63) : 63;
                         const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
-                        atomicOr((unsigned long long*)&cov[wi], (unsigned long long)mask);
+                        atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], (unsigned long long)mask);
                     }
-                    atomicOr((unsigned long long*)&mst[ms >> 6], 1ull << (ms & 63));
+                    atomicOr((unsigned long long*)&mstw[(ms >> 6) & (ZZ_L2_WIN - 1)], 1ull << (ms & 63));
+                    uint32_t sym, eb, evv, bucket;                       // GetFrequencies, :455-463
+                    length_symbol(mlen, sym, eb, evv);
+                    hist_add(histP, sym);
+                    dist_symbol(dist, bucket, eb, evv);
+                    hist_add(histP, 286 + bucket);
                 }
                 ntok += (uint32_t)__builtin_popcountll(evmask);
             }
         }
         ZZ_T(12);
+        // later matches start at >= base + 64 - 258: block (base>>6) - 5 cannot change any more
+        if (base >= 64 * ZZ_L2_LAG) {
+            ZZ_WAVE_SYNC();
+            nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, fbyte);
+            Fnext++;
+        }
+        ZZ_T(13);
         w4 = w4next;
     }
+    ZZ_WAVE_SYNC();
+    for (const uint32_t nblk = (n + 63) >> 6; Fnext < nblk; ++Fnext) {       // the tail nobody probes (:222) + the lag
+        const uint32_t p = (Fnext << 6) + (uint32_t)lane;
+        nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, p < n ? src[p] : 0u);
+    }
+    nrec_out = nrec;
 #ifdef ZZ_PROF
-    if (lane == 0 && prof) { for (int _i = 6; _i < 10; ++_i) atomicAdd(&prof[_i], prof_acc[_i]); atomicAdd(&prof[12], prof_acc[12]); }
+    if (lane == 0 && prof) { for (int _i = 6; _i < 10; ++_i) atomicAdd(&prof[_i], prof_acc[_i]); atomicAdd(&prof[12], prof_acc[12]); atomicAdd(&prof[13], prof_acc[13]); }
 #endif
     return ntok;
 }
@@ -465,14 +521,14 @@ struct zz_l2_params {
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
 };
 
-#define ZZ_L2_LDS_BYTES (16384 + 512 + 256)
+#define ZZ_L2_LDS_BYTES (16384 + 512 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
 
 __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
-    // ---- LDS carve-up: 17,152 bytes => nine workgroups per CU (with <= 168 VGPRs: three waves per SIMD). The hash
-    // table is dead once the token pass is over, so histograms, Huffman scratch and code tables all live inside it;
-    // the status bitmaps live in global scratch.
+    // ---- LDS carve-up: 17,792 bytes => nine workgroups per CU (with <= 168 VGPRs: three waves per SIMD). The hash
+    // table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the code tables
+    // all live inside it; only the bit ring, the bitmap window and the packed counters need their own space.
     __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES];
     uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table during the token pass
     uint32_t* symF = (uint32_t*)(lds + 8192);                     // 1280: 286 lit/len + pad | 30 dist at [288..318)
@@ -480,8 +536,11 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
     uint32_t* codes = (uint32_t*)(lds + 8192 + 1280);             // 1152: 286 lit/len codes
     uint32_t* dcodes = (uint32_t*)(lds + 8192 + 1280 + 1152);     // 128: 30 distance codes
     uint32_t* metaF = (uint32_t*)(lds + 8192 + 1280 + 1152 + 128);            // 80: 19 meta frequencies
+    uint32_t* misc = (uint32_t*)(lds + 11264);                    // 256: lane-0 results [0..3], code-generation work area [16..48)
     uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512
-    uint32_t* misc = (uint32_t*)(lds + 16384 + 512);              // 256: lane-0 results [0..3], code-generation work area [16..48)
+    uint64_t* covw = (uint64_t*)(lds + 16384 + 512);              // 128: covered bits of the 16 blocks around the probe front
+    uint64_t* mstw = covw + ZZ_L2_WIN;                            // 128: match-start bits
+    uint32_t* histP = (uint32_t*)(lds + 16384 + 512 + 2 * ZZ_L2_WIN * 8);     // 640: packed 16-bit counters
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -498,9 +557,8 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
     const int lane = lane_id();
     ZZ_PROF_DECL
     uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES;
-    l2_token* tokens = (l2_token*)my_scratch;
-    uint64_t* cov = (uint64_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 8);            // 4096: position covered by a match
-    uint64_t* mst = cov + 512;                                                 // 4096: position starts a match
+    uint32_t* tokens = (uint32_t*)my_scratch;                                   // matches in stream order
+    uint16_t* recs = (uint16_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 4);            // records in stream order
 
     for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
         const uint64_t off = (uint64_t)k * P.packet_size;
@@ -516,9 +574,8 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
         {
             uint4* z = (uint4*)lds;
             for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
-            uint4* zb = (uint4*)cov;
-            for (int i = lane; i < 8192 / 16; i += ZZ_WAVE) zb[i] = make_uint4(0, 0, 0, 0);   // cov, mst (global)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the zeros reach L2 before the token pass's atomics
+            uint32_t* zw = (uint32_t*)covw;
+            for (int i = lane; i < 2 * ZZ_L2_WIN * 2 + ZZ_L2_HIST_WORDS; i += ZZ_WAVE) zw[i] = 0;   // window + counters
         }
         bitring ring;
         ring_init(ring, ring_words, out);
@@ -530,65 +587,23 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
         ZZ_T(0);
 
         if (n > 0) {
-            // ================= token pass (encoder.cpp:217-248, 375-440) ===========================================
+            // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
             // loads may run a few bytes past the packet: only the last two packets can leave the buffer that way
-            const uint32_t ntok = k + 2 >= P.npk ? l2_token_pass<true>(T, cov, mst, tokens, src, end, n, before, P.prof)
-                                                 : l2_token_pass<false>(T, cov, mst, tokens, src, end, n, before, P.prof);
-            __syncthreads();   // token stores (global) are read back by other lanes below
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // bitmap words were built by L2 atomics: drop stale L1 lines
-            for (int i = lane; i < 320; i += ZZ_WAVE) symF[i] = 0;   // the hash table is dead now: its space is reused
-            if (lane < 20) metaF[lane] = 0;
-            __syncthreads();
-
-            ZZ_T(1); ZZ_C(10, 1); ZZ_C(11, ntok);
-            // ================= histograms (encoder.cpp:442-471) ===============================================
-            const uint32_t nblk = (n + 63) >> 6;
-            // 64 position blocks at a time: lane l holds block b0+l's bitmap words and its exclusive match count
-            // (a wave scan), the inner loops read them back with v_readlane -- no per-block memory access
-            {
-                uint32_t carry = 0;
-                for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
-                    const uint32_t bl = b0 + lane;
-                    const uint64_t covv = bl < nblk ? cov[bl] : 0, mstv = bl < nblk ? mst[bl] : 0;
-                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mstv);
-                    const uint32_t incl = wave_scan_incl(cnt);
-                    const uint32_t mcv = carry + incl - cnt;
-                    carry += readlane(incl, 63);
-                    const uint32_t nb_here = nblk - b0 < 64 ? nblk - b0 : 64;
-                    for (uint32_t i0 = 0; i0 < nb_here; i0 += 4) {
-                        // four blocks per trip: all loads first, so that their latencies overlap
-                        uint32_t byte[4]; uint32_t kind[4]; l2_token tk4[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t bi = i0 + i;
-                            const uint32_t q = ((b0 + bi) << 6) + lane;
-                            kind[i] = 0; byte[i] = 0; tk4[i].start = 0; tk4[i].dist = 1; tk4[i].len = 3; tk4[i].pad = 0;
-                            if (bi < nb_here) {
-                                const uint64_t cw = readlane64(covv, (int)bi), mw = readlane64(mstv, (int)bi);
-                                const uint32_t mc = readlane(mcv, (int)bi);
-                                if (q < n) {
-                                    if (!((cw >> lane) & 1)) { kind[i] = 1; byte[i] = src[q]; }
-                                    else if ((mw >> lane) & 1) {
-                                        kind[i] = 2;
-                                        tk4[i] = tokens[mc + __builtin_popcountll(mw & ((1ull << lane) - 1))];
-                                    }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (kind[i] == 1) atomicAdd(&symF[byte[i]], 1u);
-                            else if (kind[i] == 2) {
-                                uint32_t sym, eb, ev, bucket;
-                                length_symbol(tk4[i].len, sym, eb, ev);
-                                atomicAdd(&symF[sym], 1u);
-                                dist_symbol(tk4[i].dist, bucket, eb, ev);
-                                atomicAdd(&distF[bucket], 1u);
-                            }
-                        }
-                    }
-                }
+            uint32_t nbody = 0;      // records of the block body (literals + matches)
+            const uint32_t ntok = k + 2 >= P.npk
+                ? l2_token_pass<true>(T, covw, mstw, histP, tokens, recs, src, end, n, before, nbody, P.prof)
+                : l2_token_pass<false>(T, covw, mstw, histP, tokens, recs, src, end, n, before, nbody, P.prof);
+            __syncthreads();   // token / record stores (global) are read back by other lanes below
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this scratch held the previous packet's records: drop stale L1 lines
+            // the hash table is dead now: its space is reused. Unpack the counters (GetFrequencies, :442-471).
+            for (int i = lane; i < 320; i += ZZ_WAVE) {
+                uint32_t v = 0;
+                if (i < 286) v = (histP[i >> 1] >> ((i & 1) << 4)) & 0xFFFF;
+                else if (i >= 288 && i < 318) { const int j = 286 + (i - 288); v = (histP[j >> 1] >> ((j & 1) << 4)) & 0xFFFF; }
+                symF[i] = v;
             }
+            if (lane < 20) metaF[lane] = 0;
+            ZZ_T(1); ZZ_C(10, 1); ZZ_C(11, ntok);
             __syncthreads();
 
             ZZ_T(2);
@@ -675,46 +690,39 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
                 }
                 ring_append(ring, bits, nb);
             }
-            // body: WriteRecords (:149-169) by position
+            // body: WriteRecords (:149-169), 64 records per trip; the next trip's records are already in flight
             {
-                uint32_t carry = 0;
-                for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
-                    const uint32_t bl = b0 + lane;
-                    const uint64_t covv = bl < nblk ? cov[bl] : 0, mstv = bl < nblk ? mst[bl] : 0;
-                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mstv);
-                    const uint32_t incl = wave_scan_incl(cnt);
-                    const uint32_t mcv = carry + incl - cnt;
-                    carry += readlane(incl, 63);
-                    const uint32_t nb_here = nblk - b0 < 64 ? nblk - b0 : 64;
-                    for (uint32_t bi = 0; bi < nb_here; ++bi) {
-                        const uint64_t cw = readlane64(covv, (int)bi), mw = readlane64(mstv, (int)bi);
-                        const uint64_t live = ~cw | mw;                            // literal or match start
-                        if (bi + 1 < nb_here && live == 0) continue;               // block wholly inside a match
-                        const uint32_t q = ((b0 + bi) << 6) + lane;
-                        uint64_t bits = 0; uint32_t nb = 0;
-                        if (q < n && ((live >> lane) & 1)) {
-                            if (!((cw >> lane) & 1)) {
-                                const uint32_t cd = codes[src[q]];
-                                bits = cd & 0xFFFF; nb = cd >> 16;
-                            } else {
-                                const l2_token t = tokens[readlane(mcv, (int)bi) + __builtin_popcountll(mw & ((1ull << lane) - 1))];
-                                uint32_t sym, eb, ev, bucket, deb, dev;
-                                length_symbol(t.len, sym, eb, ev);
-                                const uint32_t lc = codes[sym];
-                                uint32_t ln = lc >> 16;
-                                uint64_t v = (lc & 0xFFFF) | ((uint64_t)ev << ln);          // Merge, :121-124
-                                ln += eb;
-                                dist_symbol(t.dist, bucket, deb, dev);
-                                const uint32_t dc = dcodes[bucket];
-                                v |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
-                                ln += dc >> 16;
-                                v |= (uint64_t)dev << ln;
-                                ln += deb;
-                                bits = v; nb = ln;
-                            }
-                        }
-                        ring_append64(ring, bits, nb);
+                uint32_t mc = 0;
+                uint32_t v = (uint32_t)lane < nbody ? recs[lane] : ZZ_L2_REC_NONE;
+                for (uint32_t r0 = 0; r0 < nbody; r0 += 64) {
+                    const uint32_t rn = r0 + 64 + (uint32_t)lane;
+                    const uint32_t vn = rn < nbody ? recs[rn] : ZZ_L2_REC_NONE;
+                    const bool ism = v == ZZ_L2_REC_MATCH;
+                    const uint64_t mb = ballot(ism);
+                    uint32_t t = (3u << 16) | 1u;
+                    if (ism) t = tokens[mc + mbcnt(mb)];
+                    uint64_t bits = 0; uint32_t nb = 0;
+                    if (v < ZZ_L2_REC_MATCH) {
+                        const uint32_t cd = codes[v];
+                        bits = cd & 0xFFFF; nb = cd >> 16;
+                    } else if (ism) {
+                        uint32_t sym, eb, ev, bucket, deb, dev;
+                        length_symbol(t >> 16, sym, eb, ev);
+                        const uint32_t lc = codes[sym];
+                        uint32_t ln = lc >> 16;
+                        uint64_t w = (lc & 0xFFFF) | ((uint64_t)ev << ln);          // Merge, :121-124
+                        ln += eb;
+                        dist_symbol(t & 0xFFFF, bucket, deb, dev);
+                        const uint32_t dc = dcodes[bucket];
+                        w |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
+                        ln += dc >> 16;
+                        w |= (uint64_t)dev << ln;
+                        ln += deb;
+                        bits = w; nb = ln;
                     }
+                    ring_append64(ring, bits, nb);
+                    mc += (uint32_t)__builtin_popcountll(mb);
+                    v = vn;
                 }
             }
             {   // codes[256] (:300)
