@@ -33,7 +33,7 @@ for it in range(2):
     prof = (ctypes.c_ulonglong * 16)()
     L.zz_debug_read_prof(h, prof)
 if level >= 2:
-    names = ["init+adler", "token pass", "counter unpack", "huffman (lane 0)", "codes (lane 0)", "emit"]
+    names = ["init+adler", "token pass", "counter unpack", "huffman", "codes", "emit"]
     tot = sum(prof[:6])
     print(f"level {level} input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; packets {prof[10]}, tokens/packet {prof[11] / max(1, prof[10]):.0f}, cycles/packet {tot / max(1, prof[10]):.0f} = {tot / max(1, prof[10]) / 32768:.1f} cyc/byte")
     for i, nm in enumerate(names):

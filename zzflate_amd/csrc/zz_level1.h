@@ -232,25 +232,32 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
 
         ZZ_T(2);
         // (1b) which lanes share a hash inside the group?
-        uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1));
+        // The read-back names the lane whose store landed: the same lane for every member of a set of equal
+        // hashes, a different one for different sets -- a 6-bit key, where the hash has 13 bits. Six ballots give
+        // every lane the mask of its set, whatever the number of sets (no loop over them).
+        const uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1));
         uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
-        uint64_t hardmask = 0;     // ... more than twice
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
-        while (lostmask) {         // one trip per hash value that occurs more than once: keep it lean
-            const int l0 = __builtin_ctzll(lostmask);
-            const uint32_t hv = readlane(h, l0);
-            const uint64_t set = ballot(active && h == hv);
-            if ((set >> lane) & 1) myset = set;
-            multimask |= set;
-            if (__builtin_popcountll(set) > 2) hardmask |= set;
-            lostmask &= ~set;
-        }
         uint32_t info = 0;
-        if (multimask) {
-            const uint64_t below = myset & ((1ull << lane) - 1);          // earlier lanes with my hash
-            if (below) {
-                info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 10);
-                if ((hardmask >> lane) & 1) info |= ZZ_WI_HARD;
+        if (lostmask) {
+            uint32_t W = (uint32_t)lane;
+            if (active) W = (rb - 1u - cur) & 63u;
+            uint64_t set = ~0ull;
+#pragma unroll
+            for (int kb = 0; kb < 6; ++kb) {
+                const bool bit = (W >> kb) & 1;
+                const uint64_t bm = ballot(bit);
+                set &= bit ? bm : ~bm;
+            }
+            const bool multi = (set & (set - 1)) != 0;
+            multimask = ballot(multi);
+            if (multi) {
+                myset = set;
+                const uint64_t below = set & ((1ull << lane) - 1);        // earlier lanes with my hash
+                if (below) {
+                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 10);
+                    if (__builtin_popcountll(set) > 2) info |= ZZ_WI_HARD;   // ... shared by more than two lanes
+                }
             }
         }
         ZZ_T(3);

@@ -216,6 +216,127 @@ __device__ inline void calc_lengths(huff_scratch& S, const uint32_t* freqs, int 
     }
 }
 
+// ---- the same construction, wave-cooperative (packet kernel) ------------------------------------------------------
+// Leaf setup, the length limit test and the output are parallel over symbols; only the heap replay runs on lane 0,
+// on records packed as frequency << 10 | tree index (one LDS word per heap slot: half the dependent LDS round trips
+// of the two-array form above). Frequencies stay below 2^22: a packet has < 32768 records and the floor grows by
+// at most a few units per retry. Leaves are tree items 0..n-1, so "is a leaf" is an index test and internal items
+// keep their children in one word (left | right << 16).
+#define ZZ_HKEY_SHIFT 10
+__device__ __forceinline__ void hkey_push(uint32_t* hk, int hole, int top, uint32_t v)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top) {
+        const uint32_t pk = hk[parent];
+        if (!((pk >> ZZ_HKEY_SHIFT) > (v >> ZZ_HKEY_SHIFT))) break;
+        hk[hole] = pk;
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    hk[hole] = v;
+}
+__device__ __forceinline__ void hkey_adjust(uint32_t* hk, int hole, int len, uint32_t v)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        uint32_t a = hk[child];
+        const uint32_t b = hk[child - 1];
+        if ((a >> ZZ_HKEY_SHIFT) > (b >> ZZ_HKEY_SHIFT)) { child--; a = b; }
+        hk[hole] = a;
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        hk[hole] = hk[child - 1];
+        hole = child - 1;
+    }
+    hkey_push(hk, hole, top, v);
+}
+
+// CalculateTree (huffman.cpp:67-120) for all lanes; returns the maximum leaf depth (wave-uniform)
+__device__ inline int calculate_tree_w(huff_scratch& S, const uint32_t* freqs, int n, uint32_t minFreq)
+{
+    const int lane = lane_id();
+    uint32_t* hk = S.rec_freq;                 // [288] heap records
+    uint32_t* t_lr = (uint32_t*)S.t_left;      // [576] children of internal items (t_left and t_right are adjacent)
+    uint8_t* t_bits = S.t_bits;
+    uint32_t nrec = 0;
+    for (int i0 = 0; i0 < n; i0 += ZZ_WAVE) {  // :70-83 records of the non-zero symbols, in symbol order
+        const int i = i0 + lane;
+        uint32_t f = i < n ? freqs[i] : 0;
+        const uint64_t nz = ballot(f != 0);
+        if (f != 0) {
+            if (f < minFreq) f = minFreq;
+            hk[nrec + mbcnt(nz)] = (f << ZZ_HKEY_SHIFT) | (uint32_t)i;
+        }
+        if (i < n) t_bits[i] = 0;
+        nrec += (uint32_t)__builtin_popcountll(nz);
+    }
+    ZZ_WAVE_SYNC();
+    int nt = n;
+    if (lane == 0) {
+        int nr = (int)nrec;
+        if (nr >= 2) {                         // make_heap (stl_heap.h:339-360)
+            for (int parent = (nr - 2) / 2;; --parent) {
+                hkey_adjust(hk, parent, nr, hk[parent]);
+                if (parent == 0) break;
+            }
+        }
+        while (nr >= 2) {                      // :92-104, pop_heap x2 (stl_heap.h:253-265) + push_heap
+            const uint32_t a = hk[0];
+            nr--;
+            if (nr >= 1) hkey_adjust(hk, 0, nr, hk[nr]);
+            const uint32_t b = hk[0];
+            nr--;
+            if (nr >= 1) hkey_adjust(hk, 0, nr, hk[nr]);
+            const uint32_t sum = (a >> ZZ_HKEY_SHIFT) + (b >> ZZ_HKEY_SHIFT);
+            const uint32_t mask = (1u << ZZ_HKEY_SHIFT) - 1;
+            t_lr[nt] = (a & mask) | ((b & mask) << 16);
+            nr++;
+            hkey_push(hk, nr - 1, 0, (sum << ZZ_HKEY_SHIFT) | (uint32_t)nt);
+            nt++;
+        }
+        if (nt > n) t_bits[nt - 1] = 0;
+        for (int i = nt - 1; i >= n; --i) {    // :108-118 depths, root first; leaves are handled below
+            const uint32_t lr = t_lr[i];
+            const uint8_t b = (uint8_t)(t_bits[i] + 1);
+            t_bits[lr & 0xFFFF] = b;
+            t_bits[lr >> 16] = b;
+        }
+    }
+    ZZ_WAVE_SYNC();
+    uint32_t mx = 0;                           // :109-111 deepest leaf; item 0 is never looked at (the loop stops at 1)
+    for (int i = lane; i < n; i += ZZ_WAVE)
+        if (i != 0 && t_bits[i] > mx) mx = t_bits[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)mx, o); mx = y > mx ? y : mx; }
+    return (int)uniform(mx);
+}
+
+// CalcLengths (huffman.cpp:122-154) for all lanes
+__device__ inline void calc_lengths_w(huff_scratch& S, const uint32_t* freqs, int n, int maxlen, uint8_t* out)
+{
+    const int lane = lane_id();
+    uint32_t minFreq = 0;
+    for (;;) {
+        const int mx = calculate_tree_w(S, freqs, n, minFreq);
+        if (mx <= maxlen) {
+            for (int i = lane; i < n; i += ZZ_WAVE) {
+                const uint32_t b = S.t_bits[i];
+                out[i] = freqs[i] == 0 ? 0 : (uint8_t)(b > 1 ? b : 1);
+            }
+            ZZ_WAVE_SYNC();
+            return;
+        }
+        uint32_t part = 0;
+        for (int i = lane; i < n; i += ZZ_WAVE) part += freqs[i];
+        const uint32_t step = wave_sum(part) >> maxlen;
+        minFreq += step > 1 ? step : 1;
+    }
+}
+
 // huffman.h:49-81 generate: canonical codes, stored bit-reversed, packed (len << 16) | bits; 0 for unused.
 // work: 32 words of LDS (bl_count[16], next_code[16]) -- runtime-indexed private arrays would go to scratch.
 __device__ inline void generate_codes(const uint8_t* lengths, int n, uint32_t* codes, uint32_t* work)
@@ -238,6 +359,45 @@ __device__ inline void generate_codes(const uint8_t* lengths, int n, uint32_t* c
         }
         codes[i] = v;
     }
+}
+
+// generate (huffman.h:49-81) for all lanes: symbols of one length get consecutive codes in symbol order, so a
+// symbol's code is next_code[len] + (number of earlier symbols with that length) -- counted with ballots, 64
+// symbols at a time. work: 32 words of LDS.
+__device__ inline void generate_codes_w(const uint8_t* lengths, int n, uint32_t* codes, uint32_t* work)
+{
+    const int lane = lane_id();
+    uint32_t* bl_count = work;
+    uint32_t* next_code = work + 16;
+    if (lane < 16) bl_count[lane] = 0;
+    ZZ_WAVE_SYNC();
+    for (int i = lane; i < n; i += ZZ_WAVE) { const uint32_t l = lengths[i]; if (l) atomicAdd(&bl_count[l], 1u); }
+    ZZ_WAVE_SYNC();
+    {
+        const uint32_t cnt = lane < 16 ? bl_count[lane] : 0;
+        uint32_t c = 0, mine = 0;
+        for (int b = 1; b < 16; ++b) { c = (c + readlane(cnt, b - 1)) << 1; if (lane == b) mine = c; }
+        if (lane < 16) next_code[lane] = mine;
+    }
+    ZZ_WAVE_SYNC();
+    for (int i0 = 0; i0 < n; i0 += ZZ_WAVE) {
+        const int i = i0 + lane;
+        const uint32_t len = i < n ? lengths[i] : 0;
+        uint32_t v = 0;
+        uint64_t todo = ballot(len != 0);
+        while (todo) {
+            const uint32_t lv = readlane(len, __builtin_ctzll(todo));
+            const uint64_t same = ballot(len == lv);
+            const uint32_t nc = next_code[lv];
+            ZZ_WAVE_SYNC();
+            if (len == lv) v = (len << 16) | bitrev(nc + mbcnt(same), len);
+            if (lane == 0) next_code[lv] = nc + (uint32_t)__builtin_popcountll(same);
+            ZZ_WAVE_SYNC();
+            todo &= ~same;
+        }
+        if (i < n) codes[i] = v;
+    }
+    ZZ_WAVE_SYNC();
 }
 
 // huffman.cpp:158-216 FromLengths/AddRecords: RLE of one code-length array into (value, payload) records,
@@ -342,20 +502,26 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         // next block's hash bytes: in flight during the rest of this block
         const uint32_t w4next = q + 64 < n ? ld32<SAFE>(src + q + 64, end) : 0;
         ZZ_WAVE_SYNC();
+        // Positions of this block that share a hash: the read-back names the lane whose store landed, the same
+        // lane for every member of a set and a different one for different sets -- a 6-bit key. Six ballots give
+        // every lane the mask of its set (no loop over sets); the candidate of a later member is the nearest
+        // earlier member, and the table must end up holding the last member.
         uint32_t rb = 0;
         if (ins) rb = T[h];
-        uint64_t lostmask = ballot(ins && rb != ((q + 1) & 0xFFFF));
         uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
-        while (lostmask) {
-            const int l0 = __builtin_ctzll(lostmask);
-            const uint32_t hv = readlane(h, l0);
-            const bool mine = ins && h == hv;
-            const uint64_t set = ballot(mine);
+        if (ballot(ins && rb != q + 1)) {
+            const uint32_t W = ins ? (rb - 1u - base) & 63u : (uint32_t)lane;
+            uint64_t set = ~0ull;
+#pragma unroll
+            for (int kb = 0; kb < 6; ++kb) {
+                const bool bit = (W >> kb) & 1;
+                const uint64_t bm = ballot(bit);
+                set &= bit ? bm : ~bm;
+            }
             const uint64_t below = set & ((1ull << lane) - 1);
-            if (mine && below) cand1 = base + (63 - __builtin_clzll(below)) + 1;   // nearest earlier member
+            if (ins && below) cand1 = base + (63 - __builtin_clzll(below)) + 1;   // nearest earlier member
             ZZ_WAVE_SYNC();
-            if (mine && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);          // highest member wins
-            lostmask &= ~set;
+            if (ins && W != (uint32_t)lane && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);   // last member wins
         }
         ZZ_WAVE_SYNC();
         skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
@@ -607,37 +773,36 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
             __syncthreads();
 
             ZZ_T(2);
-            // ================= code construction (lane 0) =====================================================
-            if (lane == 0) {
-                symF[256] += 1;                                                  // :470
-                int64_t bits = 0;
-                calc_lengths(S, symF, 286, 15, lens);                            // ComputeCodes, :171-176
-                int nrec = rle_lengths(lens, 286, rle, 0, metaF);
-                const int nSymRecs = nrec;
-                for (int i = 0; i < 286; ++i) {                                  // CountBits, :178-187
-                    uint32_t eb = i < 265 || i == 285 ? 0 : (uint32_t)(i - 261) >> 2;
-                    bits += (int64_t)symF[i] * (lens[i] + eb);
-                }
-                calc_lengths(S, distF, 30, 15, lens + 288);
-                nrec = rle_lengths(lens + 288, 30, rle, nrec, metaF);
-                for (int i = 0; i < 30; ++i) {
-                    uint32_t eb = i < 4 ? 0 : (uint32_t)(i - 2) >> 1;
-                    bits += (int64_t)distF[i] * (lens[288 + i] + eb);
-                }
-                calc_lengths(S, metaF, 19, 7, metaLens);                         // :263-265
-                int64_t total = 3 + 5 + 5 + 4 + 3 * 19 + bits;                   // :267
-                for (int i = 0; i < nrec; ++i) {                                 // WriteLengths<LengthCounter>, :20-46
-                    const uint32_t v = rle[i] & 0xFF;
-                    total += metaLens[v] + (v == 16 ? 2 : v == 17 ? 3 : v == 18 ? 7 : 0);
-                }
-                misc[0] = (uint32_t)((total + 8) / 8);                           // requiredLength, :271
-                misc[1] = (uint32_t)nSymRecs;
-                misc[2] = (uint32_t)nrec;
+            // ================= code construction =================================================================
+            if (lane == 0) symF[256] += 1;                                       // :470
+            ZZ_WAVE_SYNC();
+            calc_lengths_w(S, symF, 286, 15, lens);                              // ComputeCodes, :171-176
+            uint32_t bitsum = 0;
+            for (int i = lane; i < 286; i += ZZ_WAVE) {                          // CountBits, :178-187
+                const uint32_t eb = i < 265 || i == 285 ? 0 : (uint32_t)(i - 261) >> 2;
+                bitsum += symF[i] * (lens[i] + eb);
             }
+            calc_lengths_w(S, distF, 30, 15, lens + 288);
+            if (lane < 30) {
+                const uint32_t eb = lane < 4 ? 0 : (uint32_t)(lane - 2) >> 1;
+                bitsum += distF[lane] * (lens[288 + lane] + eb);
+            }
+            if (lane == 0) {
+                int nr = rle_lengths(lens, 286, rle, 0, metaF);
+                misc[1] = (uint32_t)nr;
+                misc[2] = (uint32_t)rle_lengths(lens + 288, 30, rle, nr, metaF);
+            }
+            ZZ_WAVE_SYNC();
+            calc_lengths_w(S, metaF, 19, 7, metaLens);                           // :263-265
+            const uint32_t nrec = misc[2];
+            for (uint32_t i = lane; i < nrec; i += ZZ_WAVE) {                    // WriteLengths<LengthCounter>, :20-46
+                const uint32_t v = rle[i] & 0xFF;
+                bitsum += metaLens[v] + (v == 16 ? 2 : v == 17 ? 3 : v == 18 ? 7 : 0);
+            }
+            const uint32_t total = 3 + 5 + 5 + 4 + 3 * 19 + wave_sum(bitsum);    // :267
+            const uint32_t required = (total + 8) / 8;                           // requiredLength, :271
             __syncthreads();
             ZZ_T(3);
-            const uint32_t required = misc[0];
-            const uint32_t nrec = misc[2];
 
             if (required >= n) {
                 // ================= UncompressedFallback (encoder.cpp:305-317, 482-502) ==========================
@@ -662,11 +827,9 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
             }
 
             // ================= dynamic block ====================================================================
-            if (lane == 0) {
-                generate_codes(lens, 286, codes, misc + 16);                      // huffman::generate
-                generate_codes(lens + 288, 30, dcodes, misc + 16);
-                generate_codes(metaLens, 19, metaCodes, misc + 16);
-            }
+            generate_codes_w(lens, 286, codes, misc + 16);                        // huffman::generate
+            generate_codes_w(lens + 288, 30, dcodes, misc + 16);
+            generate_codes_w(metaLens, 19, metaCodes, misc + 16);
             __syncthreads();
             ZZ_T(4);
             // StartBlock(UserDefinedHuffman, final) + HLIT=29 HDIST=29 HCLEN=15 (:280-285)
