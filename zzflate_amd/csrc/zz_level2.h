@@ -478,7 +478,12 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
     uint32_t nextProbe = 1;         // j (:383)
     uint32_t batchEnd = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
     uint32_t skipPos = 0;           // position that must not be inserted in the current block (0 = byte 0)
-    uint32_t w4 = (uint32_t)lane < n ? ld32<SAFE>(src + lane, end) : 0;
+    // this lane's own bytes: 16 from its position (hash + forward compare) and the 8 in front (backward compare)
+    uint64_t wa = 0, wa2 = 0, wb = 0;
+    if ((uint32_t)lane < n) {
+        ld128<SAFE>(src + lane, end, wa, wa2);
+        if (before + (uint32_t)lane >= 8) wb = load64(src + (int64_t)lane - 8);
+    }
     for (uint32_t base = 0; base < target; base += 64) {
         if (base >= batchEnd) {
             // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first
@@ -496,11 +501,23 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         uint32_t fbyte = 0;
         if (base >= 64 * ZZ_L2_LAG) fbyte = src[q - 64 * ZZ_L2_LAG];
         const bool ins = q < n && q != skipPos && q != 0;
-        const uint32_t h = calc_hash3(w4);                            // CalcHash(source + j), :388
+        const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
+        const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
         uint32_t old = 0;
         if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1); }            // :389-390 / :474-480
-        // next block's hash bytes: in flight during the rest of this block
-        const uint32_t w4next = q + 64 < n ? ld32<SAFE>(src + q + 64, end) : 0;
+        // the table candidate's bytes are requested at once (a lane whose candidate turns out to sit in this very
+        // block takes that lane's registers instead): 16 at the candidate (:399), 8 in front of it (:92-102)
+        uint64_t ca = 0, ca2 = 0, cpre = 0;
+        if (doProbe && ins && old != 0 && q < batchEnd) {
+            ld128<SAFE>(src + (old - 1), end, ca, ca2);
+            if (before + (old - 1) >= 8) cpre = load64(src + (int64_t)(old - 1) - 8);
+        }
+        // next block's own bytes: in flight during the rest of this block
+        uint64_t wan = 0, wan2 = 0, wbn = 0;
+        if (q + 64 < n) {
+            ld128<SAFE>(src + q + 64, end, wan, wan2);
+            wbn = load64(src + q + 56);
+        }
         ZZ_WAVE_SYNC();
         // Positions of this block that share a hash: the read-back names the lane whose store landed, the same
         // lane for every member of a set and a different one for different sets -- a 6-bit key. Six ballots give
@@ -509,6 +526,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         uint32_t rb = 0;
         if (ins) rb = T[h];
         uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
+        int inlane = -1;                                              // >= 0: the candidate is that lane of this block
         if (ballot(ins && rb != q + 1)) {
             const uint32_t W = ins ? (rb - 1u - base) & 63u : (uint32_t)lane;
             uint64_t set = ~0ull;
@@ -519,7 +537,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                 set &= bit ? bm : ~bm;
             }
             const uint64_t below = set & ((1ull << lane) - 1);
-            if (ins && below) cand1 = base + (63 - __builtin_clzll(below)) + 1;   // nearest earlier member
+            if (ins && below) { inlane = 63 - __builtin_clzll(below); cand1 = base + (uint32_t)inlane + 1; }   // nearest earlier member
             ZZ_WAVE_SYNC();
             if (ins && W != (uint32_t)lane && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);   // last member wins
         }
@@ -527,20 +545,25 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
 
         ZZ_T(7);
-        if (base + 64 > nextProbe && nextProbe < batchEnd) {
+        if (doProbe) {
             // ---- quick compare info for all 64 probes of this block --------------------------------------
             const bool has = ins && cand1 != 0 && q < batchEnd;
             const uint32_t c = cand1 - 1;
+            if (ballot(inlane >= 0)) {
+                // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
+                const int sl = inlane >= 0 ? inlane : lane;
+                const uint64_t sa = ((uint64_t)(uint32_t)__shfl((int)(wa >> 32), sl) << 32) | (uint32_t)__shfl((int)wa, sl);
+                const uint64_t sa2 = ((uint64_t)(uint32_t)__shfl((int)(wa2 >> 32), sl) << 32) | (uint32_t)__shfl((int)wa2, sl);
+                const uint64_t sp = ((uint64_t)(uint32_t)__shfl((int)(wb >> 32), sl) << 32) | (uint32_t)__shfl((int)wb, sl);
+                if (inlane >= 0) { ca = sa; ca2 = sa2; cpre = sp; }
+            }
             uint32_t fwd8 = 0, bwd8 = 0, room = 0;
             if (has) {
-                uint64_t qa, qb, ca, cbb;                                // 16 bytes at the probe and at the candidate (:399)
-                ld128<SAFE>(src + q, end, qa, qb);
-                ld128<SAFE>(src + c, end, ca, cbb);
-                const uint64_t x = qa ^ ca, x2 = qb ^ cbb;
+                const uint64_t x = wa ^ ca, x2 = wa2 ^ ca2;            // 16 bytes at the probe and at the candidate (:399)
                 const uint64_t cb = before + c;                        // bytes in front of the candidate
                 room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
                 if (room >= 8) {
-                    const uint64_t y = load64(src + (int64_t)q - 8) ^ load64(src + (int64_t)c - 8);
+                    const uint64_t y = wb ^ cpre;
                     bwd8 = y ? (uint32_t)__builtin_clzll(y) >> 3 : 8;
                 } else {
                     while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
@@ -550,90 +573,123 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
             const uint32_t broom = bwd8 < room ? bwd8 : room;
             ZZ_DRAIN();
             ZZ_T(8);
-            // ---- the greedy walk: tokens stay in their probe lane until the block is done ----------------------
-            // Scalar code is slow here (tools/ubench_scalar.hip), so tokens whose lengths are known (< 16 forward,
-            // < 8 backward) are found by a hand-written loop; "8 or more" drops out to the C++ below.
-            uint64_t evmask = 0;
-            uint32_t tk = 0;            // start | len << 16 of the token found at this lane's probe
-            const uint64_t hasmask = ballot(has);
-            const uint32_t ubase = uniform(base);
+            // ---- the greedy walk ----------------------------------------------------------------------------------
+            // A probe at lane l is a match when fwd8 + min(l - backRefEnd, broom) >= 4 (:404-407). "Strong" lanes
+            // (fwd8 >= 4) are matches whatever the parse did before; "weak" ones need `need` pending literals.
+            // After a match backRefEnd = probe + fwd8 whatever the backward part was (:416,422), so the scalar loop
+            // only hops from match to match (scalar code is slow here: tools/ubench_scalar.hip) and marks the lanes;
+            // starts and lengths are computed for all marked lanes at once afterwards. Lengths of "16 or more"
+            // forward / "8 or more" backward drop out to the C++ below.
+            const bool strong = has && fwd8 >= 4;
+            const bool weak = has && fwd8 < 4 && fwd8 + broom >= 4;
+            const uint64_t Smask = ballot(strong);
+            const uint64_t Amask = Smask | ballot(weak);
+            uint32_t winfo = fwd8 | ((weak ? 4 - fwd8 : 0) << 5) | (broom == 8 ? 0x100u : 0) | (fwd8 == 16 ? 0x200u : 0);
+            {
+                const uint32_t endl = (uint32_t)lane + fwd8 + 1;                  // first lane probed after a match here
+                const uint64_t m = endl >= 64 ? 0 : (Amask & (~0ull << endl));
+                winfo |= (m ? (uint32_t)__builtin_ctzll(m) : 64u) << 16;
+            }
+            uint32_t endp = q + fwd8;       // backRefEnd after a match at this lane (slow tokens overwrite theirs)
+            uint32_t tk = 0;                // start | len << 16, slow tokens only; the others are filled in below
+            uint64_t evmask = 0, slowmask = 0;
+            const uint32_t Bentry = B;
             for (;;) {
                 uint32_t np = nextProbe > base ? nextProbe - base : 0;   // first lane that may be probed
                 if (np >= 64) break;
                 uint32_t slow = 0;
-                B = uniform(B); np = uniform(np);   // the compiler does not always see that these are wave-uniform
+                int32_t Brel = (int32_t)uniform(B - base);               // the compiler does not always see that these are wave-uniform
+                np = uniform(np);
                 {
-                    uint32_t t1, t2, sf, sb, val, qe;
+                    uint32_t inf, t1, t2;
                     uint64_t tmp;
                     int32_t e;
                     asm volatile(
                         "1:\n\t"
-                        "v_subrev_u32 %[t1], %[B], %[q]\n\t"          // pend = q - backRefEnd (:404)
-                        "v_min_u32 %[t1], %[t1], %[broom]\n\t"        // backward part that may be used
-                        "v_add_u32 %[t2], %[t1], %[fwd8]\n\t"
-                        "v_cmp_le_u32 vcc, 4, %[t2]\n\t"              // :406-407
                         "s_lshl_b64 %[tmp], -1, %[np]\n\t"
-                        "s_and_b64 %[tmp], %[tmp], vcc\n\t"
-                        "s_and_b64 %[tmp], %[tmp], %[hasmask]\n\t"
-                        "s_ff1_i32_b64 %[e], %[tmp]\n\t"
+                        "s_and_b64 %[tmp], %[tmp], %[A]\n\t"
+                        "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first candidate at or after np (-1: none)
                         "s_cmp_lt_i32 %[e], 0\n\t"
-                        "s_cbranch_scc1 3f\n\t"                       // no further token in this block
-                        "v_readlane_b32 %[sf], %[fwd8], %[e]\n\t"
-                        "v_readlane_b32 %[sb], %[t1], %[e]\n\t"
-                        "s_cmp_eq_u32 %[sf], 16\n\t"
-                        "s_cbranch_scc1 2f\n\t"                       // forward "16 or more": extend in C++
-                        "s_cmp_eq_u32 %[sb], 8\n\t"
-                        "s_cbranch_scc1 2f\n\t"                       // backward "8 or more"
-                        "s_add_u32 %[val], %[sf], %[sb]\n\t"          // match length (:406), <= 22
-                        "s_add_u32 %[qe], %[base], %[e]\n\t"
-                        "s_sub_u32 %[qe], %[qe], %[sb]\n\t"           // match start (:416)
-                        "s_add_u32 %[B], %[qe], %[val]\n\t"           // backRefEnd (:422)
-                        "s_lshl_b32 %[val], %[val], 16\n\t"
-                        "s_or_b32 %[val], %[val], %[qe]\n\t"
-                        "v_mov_b32 %[t2], %[val]\n\t"
-                        "v_cmp_eq_u32 vcc, %[e], %[lanev]\n\t"
-                        "v_cndmask_b32 %[tk], %[tk], %[t2], vcc\n\t"  // the token stays in its probe lane (:420)
-                        "s_bitset1_b64 %[ev], %[e]\n\t"
-                        "s_add_u32 %[np], %[B], 1\n\t"                // j = backRefEnd + 1 (:424)
-                        "s_sub_u32 %[np], %[np], %[base]\n\t"
+                        "s_cbranch_scc1 3f\n"
+                        "9:\n\t"
+                        "v_readlane_b32 %[inf], %[winfo], %[e]\n\t"
+                        "s_bitcmp1_b64 %[S], %[e]\n\t"
+                        "s_cbranch_scc0 6f\n"                        // weak: look at the pending literals
+                        "7:\n\t"
+                        "s_and_b32 %[t1], %[inf], 0x300\n\t"        // "8 or more" backward possible | "16 or more" forward
+                        "s_cmp_eq_u32 %[t1], 0\n\t"
+                        "s_cbranch_scc0 4f\n"
+                        "8:\n\t"
+                        "s_bitset1_b64 %[ev], %[e]\n\t"             // a match is found at this probe (:406-407)
+                        "s_and_b32 %[t1], %[inf], 31\n\t"
+                        "s_add_i32 %[Brel], %[e], %[t1]\n\t"        // backRefEnd (:422), relative to the block
+                        "s_add_u32 %[np], %[Brel], 1\n\t"           // j = backRefEnd + 1 (:424)
+                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"       // hop: the first candidate at or after that
+                        "s_cmp_lt_u32 %[e], 64\n\t"
+                        "s_cbranch_scc1 9b\n\t"
+                        "s_branch 3f\n"
+                        "6:\n\t"
+                        "s_sub_i32 %[t1], %[e], %[Brel]\n\t"        // pending literals j - backRefEnd (:404)
+                        "s_bfe_u32 %[t2], %[inf], 0x30005\n\t"
+                        "s_cmp_ge_i32 %[t1], %[t2]\n\t"
+                        "s_cbranch_scc1 7b\n\t"
+                        "s_add_u32 %[np], %[e], 1\n\t"              // no match at this probe: j++ (:430)
                         "s_cmp_lt_u32 %[np], 64\n\t"
                         "s_cbranch_scc1 1b\n\t"
                         "s_branch 3f\n"
+                        "4:\n\t"
+                        "s_bitcmp1_b32 %[inf], 9\n\t"
+                        "s_cbranch_scc1 2f\n\t"                     // forward "16 or more": extend in C++
+                        "s_sub_i32 %[t1], %[e], %[Brel]\n\t"
+                        "s_cmp_ge_i32 %[t1], 8\n\t"
+                        "s_cbranch_scc0 8b\n"                        // fewer than 8 pending literals: the backward part is exact
                         "2:\n\t"
+                        "s_mov_b32 %[np], %[e]\n\t"
                         "s_mov_b32 %[slow], 1\n"
                         "3:\n\t"
-                        : [B] "+s"(B), [np] "+s"(np), [ev] "+s"(evmask), [tk] "+v"(tk), [slow] "+s"(slow), [t1] "=&v"(t1),
-                          [t2] "=&v"(t2), [sf] "=&s"(sf), [sb] "=&s"(sb), [val] "=&s"(val), [qe] "=&s"(qe), [tmp] "=&s"(tmp),
-                          [e] "=&s"(e)
-                        : [q] "v"(q), [broom] "v"(broom), [fwd8] "v"(fwd8), [hasmask] "s"(hasmask), [base] "s"(ubase), [lanev] "v"((uint32_t)lane)
-                        : "vcc", "scc");
+                        : [Brel] "+s"(Brel), [np] "+s"(np), [ev] "+s"(evmask), [slow] "+s"(slow), [inf] "=&s"(inf),
+                          [t1] "=&s"(t1), [t2] "=&s"(t2), [tmp] "=&s"(tmp), [e] "=&s"(e)
+                        : [winfo] "v"(winfo), [S] "s"(Smask), [A] "s"(Amask)
+                        : "scc");
                 }
+                B = base + (uint32_t)Brel;
                 nextProbe = base + np;
                 if (!slow) break;
-                // one token with a length of "8 or more"
-                const uint32_t pend = q - B;                            // j - backRefEnd (:404)
-                const uint32_t bq = broom < pend ? broom : pend;
-                const uint64_t m = ballot(has && q >= nextProbe && fwd8 + bq >= 4);   // :406-407
-                if (!m) break;
-                const int e = __builtin_ctzll(m);
+                // one token with a length of "8 or more" backward or "16 or more" forward, at lane np
+                const int e = (int)np;
                 const uint32_t qe = base + (uint32_t)e;
                 uint32_t fwd = readlane(fwd8, e);
-                uint32_t bw = readlane(bq, e);
+                const uint32_t pe = qe - B;                              // j - backRefEnd (:404)
+                const uint32_t bre = readlane(broom, e);
+                uint32_t bw = bre < pe ? bre : pe;
                 {
                     const uint32_t ce = readlane(c, e);
                     if (fwd == 16) fwd = wave_extend_match<SAFE>(src, qe, ce, ZZ_MAX_LEN, end, 16);    // remain(), :64-90
-                    const uint32_t re = readlane(room, e), pe = qe - B;
+                    const uint32_t re = readlane(room, e);
                     const uint32_t blim = re < pe ? re : pe;
                     if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
                 }
                 uint32_t mlen = fwd + bw;
                 if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                           // :412-415
                 const uint32_t ms = qe - bw;                                                        // :416
-                if (lane == e) tk = ms | (mlen << 16);                                              // :420
-                evmask |= 1ull << e;
                 B = ms + mlen;                                                                      // :422
+                if (lane == e) { tk = ms | (mlen << 16); endp = B; }                                // :420
+                evmask |= 1ull << e;
+                slowmask |= 1ull << e;
                 nextProbe = B + 1;                                                                  // :424
                 if (nextProbe >= base + 64) break;
+            }
+            // starts and lengths of the matches the scalar loop marked: the backward part is limited by the literals
+            // pending since the previous match of this block (or since the block was entered)
+            if (evmask & ~slowmask) {
+                const uint64_t prev = evmask & ((1ull << lane) - 1);
+                const int pl = prev ? 63 - __builtin_clzll(prev) : lane;
+                const uint32_t pend_end = (uint32_t)__shfl((int)endp, pl);
+                if (((evmask & ~slowmask) >> lane) & 1) {
+                    const uint32_t pe = q - (prev ? pend_end : Bentry);
+                    const uint32_t bq = broom < pe ? broom : pe;
+                    tk = (q - bq) | ((fwd8 + bq) << 16);
+                }
             }
             ZZ_T(9);
             // ---- publish this block's tokens and their bitmap bits, all event lanes at once ----------------
@@ -668,7 +724,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
             Fnext++;
         }
         ZZ_T(13);
-        w4 = w4next;
+        wa = wan; wa2 = wan2; wb = wbn;
     }
     ZZ_WAVE_SYNC();
     for (const uint32_t nblk = (n + 63) >> 6; Fnext < nblk; ++Fnext) {       // the tail nobody probes (:222) + the lag
