@@ -89,6 +89,22 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 #define ZZ_WI_NEXT(i) (((i) >> 20) & 127u)   // plain matches: first event lane at or after the match end (64 = none)
 #define ZZ_WI_CAP 16u                        // bytes compared up front (two 8-byte words per lane)
 
+// One hop of the walk's inner loop: a plain match at event lane e (length lenA < 16 against the table candidate),
+// then e = the first event at or after its end. Unrolled twice below (four times measured slower): a taken branch costs about five scalar
+// instructions, so only every other hop pays for one.
+#define ZZ_L1_HOP \
+        "v_readlane_b32 %[inf], %[info], %[e]\n\t" \
+        "s_and_b32 %[len], %[inf], 0x70000\n\t"     /* DUP | HARD | EXTA */ \
+        "s_cmp_eq_u32 %[len], 0\n\t" \
+        "s_cbranch_scc0 4f\n\t" \
+        "s_and_b32 %[len], %[inf], 31\n\t"          /* plain match, length lenA (encoder.cpp:350-354) */ \
+        "s_bitset1_b64 %[mst], %[e]\n\t"            /* a match starts here (encoder.cpp:356) */ \
+        "s_bfm_b64 %[tmp], %[len], %[e]\n\t"        /* lanes e .. e+len-1 */ \
+        "s_or_b64 %[cov], %[cov], %[tmp]\n\t" \
+        "s_add_u32 %[pos], %[e], %[len]\n\t"        /* encoder.cpp:361-362 */ \
+        "s_bfe_u32 %[e], %[inf], 0x70014\n\t"       /* hop to the next event at or after the match end */ \
+        "s_cmp_lt_u32 %[e], 64\n\t"
+
 // The inner loop of the walk (encoder.cpp:341-368 replayed over ballot masks), hand-written because scalar code
 // is slow on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip).
 //   E    : lanes that may start a match          info : per-lane packed walk info (ZZ_WI_*), VGPR
@@ -114,18 +130,8 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cmp_lt_i32 %[e], 0\n\t"
         "s_cbranch_scc1 3f\n"
         "9:\n\t"
-        "v_readlane_b32 %[inf], %[info], %[e]\n\t"
-        "s_and_b32 %[len], %[inf], 0x70000\n\t"     // DUP | HARD | EXTA
-        "s_cmp_eq_u32 %[len], 0\n\t"
-        "s_cbranch_scc0 4f\n\t"
-        "s_and_b32 %[len], %[inf], 31\n\t"          // plain match, length lenA (encoder.cpp:350-354)
-        "s_bitset1_b64 %[mst], %[e]\n\t"            // a match starts here (encoder.cpp:356)
-        "s_bfm_b64 %[tmp], %[len], %[e]\n\t"        // lanes e .. e+len-1
-        "s_or_b64 %[cov], %[cov], %[tmp]\n\t"
-        "s_add_u32 %[pos], %[e], %[len]\n\t"        // encoder.cpp:361-362
-        "s_bfe_u32 %[e], %[inf], 0x70014\n\t"       // hop to the next event at or after the match end
-        "s_cmp_lt_u32 %[e], 64\n\t"
-        "s_cbranch_scc1 9b\n\t"
+        ZZ_L1_HOP "s_cbranch_scc0 3f\n\t"
+        ZZ_L1_HOP "s_cbranch_scc1 9b\n\t"
         "s_branch 3f\n"
         "5:\n\t"
         "s_bitset1_b64 %[mst], %[e]\n\t"            // (matches found through the in-group candidate logic)

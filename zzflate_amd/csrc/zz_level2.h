@@ -460,6 +460,22 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
     return len < maxlen ? len : maxlen;
 }
 
+// One hop of the level-2 walk: a match at candidate lane e if it is strong and its lengths are exact, then e = the
+// first candidate at or after the next probe position.
+#define ZZ_L2_HOP \
+                        "v_readlane_b32 %[inf], %[winfo], %[e]\n\t" \
+                        "s_bitcmp1_b64 %[S], %[e]\n\t" \
+                        "s_cbranch_scc0 6f\n\t"                     /* weak: look at the pending literals */ \
+                        "s_and_b32 %[t1], %[inf], 0x300\n\t"        /* "8 or more" backward possible | "16 or more" forward */ \
+                        "s_cmp_eq_u32 %[t1], 0\n\t" \
+                        "s_cbranch_scc0 4f\n\t" \
+                        "s_bitset1_b64 %[ev], %[e]\n\t"             /* a match is found at this probe (:406-407) */ \
+                        "s_and_b32 %[t1], %[inf], 31\n\t" \
+                        "s_add_i32 %[Brel], %[e], %[t1]\n\t"        /* backRefEnd (:422), relative to the block */ \
+                        "s_add_u32 %[np], %[Brel], 1\n\t"           /* j = backRefEnd + 1 (:424) */ \
+                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"       /* hop: the first candidate at or after that */ \
+                        "s_cmp_lt_u32 %[e], 64\n\t"
+
 // ---- token pass ------------------------------------------------------------------------------------------------
 // FirstPass + AddHashEntries over the whole packet (encoder.cpp:217-248, 375-440, 474-480). Returns the number
 // of matches written to `tokens` (ascending start) and, through nrec_out, the number of records in `recs`.
@@ -611,10 +627,14 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                         "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first candidate at or after np (-1: none)
                         "s_cmp_lt_i32 %[e], 0\n\t"
                         "s_cbranch_scc1 3f\n"
+                        // strong lanes without flags: two hops per taken branch (a taken branch costs about five
+                        // scalar instructions)
                         "9:\n\t"
-                        "v_readlane_b32 %[inf], %[winfo], %[e]\n\t"
-                        "s_bitcmp1_b64 %[S], %[e]\n\t"
-                        "s_cbranch_scc0 6f\n"                        // weak: look at the pending literals
+                        ZZ_L2_HOP "s_cbranch_scc0 3f\n\t"
+                        ZZ_L2_HOP "s_cbranch_scc1 9b\n\t"
+                        "s_branch 3f\n"
+                        // the same, entered half way: weak lanes that passed their test (7) and flagged lanes whose
+                        // lengths are exact after all (8)
                         "7:\n\t"
                         "s_and_b32 %[t1], %[inf], 0x300\n\t"        // "8 or more" backward possible | "16 or more" forward
                         "s_cmp_eq_u32 %[t1], 0\n\t"
