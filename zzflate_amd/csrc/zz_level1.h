@@ -248,13 +248,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         if (lostmask) {
             uint32_t W = (uint32_t)lane;
             if (active) W = (rb - 1u - cur) & 63u;
-            uint64_t set = ~0ull;
-#pragma unroll
-            for (int kb = 0; kb < 6; ++kb) {
-                const bool bit = (W >> kb) & 1;
-                const uint64_t bm = ballot(bit);
-                set &= bit ? bm : ~bm;
-            }
+            const uint64_t set = wave_match6(W);
             const bool multi = (set & (set - 1)) != 0;
             multimask = ballot(multi);
             if (multi) {

@@ -545,13 +545,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         int inlane = -1;                                              // >= 0: the candidate is that lane of this block
         if (ballot(ins && rb != q + 1)) {
             const uint32_t W = ins ? (rb - 1u - base) & 63u : (uint32_t)lane;
-            uint64_t set = ~0ull;
-#pragma unroll
-            for (int kb = 0; kb < 6; ++kb) {
-                const bool bit = (W >> kb) & 1;
-                const uint64_t bm = ballot(bit);
-                set &= bit ? bm : ~bm;
-            }
+            const uint64_t set = wave_match6(W);
             const uint64_t below = set & ((1ull << lane) - 1);
             if (ins && below) { inlane = 63 - __builtin_clzll(below); cand1 = base + (uint32_t)inlane + 1; }   // nearest earlier member
             ZZ_WAVE_SYNC();

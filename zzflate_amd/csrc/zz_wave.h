@@ -61,6 +61,22 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t x)
     return x;
 }
 
+// Lanes holding the same 6-bit key as this lane (keys are lane ids, so six ballots decide it for all lanes at once).
+// Per bit: the ballot, "my bit as a mask" (bfe on the complemented key) and one v_bitop3 per half: (ballot ^ ~mybit) & set.
+__device__ __forceinline__ uint64_t wave_match6(uint32_t key)
+{
+    const uint32_t nkey = ~key;
+    uint32_t lo = ~0u, hi = ~0u;
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+        const uint64_t bm = __ballot((key >> kb) & 1);
+        const uint32_t nm = (uint32_t)(((int32_t)(nkey << (31 - kb))) >> 31);   // all ones where my bit is clear
+        lo = __builtin_amdgcn_bitop3_b32((uint32_t)bm, nm, lo, 0x28);          // (a ^ b) & c
+        hi = __builtin_amdgcn_bitop3_b32((uint32_t)(bm >> 32), nm, hi, 0x28);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ---- loads ------------------------------------------------------------------------------------
 // gfx950 runs with unaligned global access enabled (amdhsa), so a byte-addressed 4/8-byte load is one
 // global_load_dword/dwordx2. `end` is one past the last readable byte: a load that would cross it is
