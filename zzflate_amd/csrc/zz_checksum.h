@@ -164,51 +164,62 @@ __global__ __launch_bounds__(ZZ_RED_THREADS) void k_cks_reduce(const zz_cks* cks
                                                                uint64_t n, int kind, zz_cks_total* out)
 {
     __shared__ uint32_t sa[ZZ_RED_THREADS], sb[ZZ_RED_THREADS];
-    __shared__ uint64_t sl[ZZ_RED_THREADS];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (npk + ZZ_RED_THREADS - 1) / ZZ_RED_THREADS;
     uint32_t k0 = t * per, k1 = k0 + per;
     if (k0 > npk) k0 = npk;
     if (k1 > npk) k1 = npk;
-    uint64_t a = 0, b = 0, len = 0;
+    if (kind == ZZ_CKS_ADLER) {
+        // adler.cpp:5-15 (combine), unrolled over all packets: with start-value-0 partials (a_k, b_k),
+        //   A = sum a_k,  B = sum b_k + a_k * (bytes after packet k)      (mod 65521)
+        // every term stands alone, so the fold is a plain parallel sum; a_k and the reduced byte count are below
+        // 2^16, the products below 2^32.
+        uint64_t sumA = 0, sumB = 0;
+        if (k0 < k1) {
+            const uint64_t e0 = (uint64_t)(k0 + 1) * packet_size;
+            uint32_t r = (uint32_t)((n - (e0 < n ? e0 : n)) % ZZ_ADLER_MOD);      // bytes after packet k0
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t ak = cks[k].a, bk = cks[k].b;
+                sumA += ak;
+                sumB += bk + (uint64_t)ak * r;
+                if (k + 1 < k1) {
+                    const uint64_t off = (uint64_t)(k + 1) * packet_size;
+                    const uint32_t l = (uint32_t)((n - off) < packet_size ? (n - off) : packet_size);
+                    r = (r + ZZ_ADLER_MOD - l % ZZ_ADLER_MOD) % ZZ_ADLER_MOD;
+                }
+            }
+        }
+        sa[t] = (uint32_t)(sumA % ZZ_ADLER_MOD); sb[t] = (uint32_t)(sumB % ZZ_ADLER_MOD);
+        __syncthreads();
+        for (uint32_t d = ZZ_RED_THREADS / 2; d >= 1; d >>= 1) {       // 1024 values below 2^16: no overflow
+            if (t < d) { sa[t] += sa[t + d]; sb[t] += sb[t + d]; }
+            __syncthreads();
+        }
+        if (t == 0) { out->a = sa[0] % ZZ_ADLER_MOD; out->b = sb[0] % ZZ_ADLER_MOD; out->len = n; }
+        return;
+    }
+    uint32_t a = 0;
+    uint64_t len = 0;
     const uint32_t xp = kind == ZZ_CKS_CRC ? gf2_xpow8(packet_size) : 0;
     for (uint32_t k = k0; k < k1; ++k) {
         uint64_t off = (uint64_t)k * packet_size;
         uint64_t l = (n - off) < packet_size ? (n - off) : packet_size;
-        if (kind == ZZ_CKS_ADLER) {
-            b = (b + cks[k].b + (l % ZZ_ADLER_MOD) * a) % ZZ_ADLER_MOD;
-            a = (a + cks[k].a) % ZZ_ADLER_MOD;
-        } else {
-            uint32_t sh = l == packet_size ? xp : gf2_xpow8(l);
-            a = gf2_mulmod((uint32_t)a, sh) ^ cks[k].a;
-        }
+        uint32_t sh = l == packet_size ? xp : gf2_xpow8(l);
+        a = gf2_mulmod(a, sh) ^ cks[k].a;
         len += l;
     }
     if (kind == ZZ_CKS_CRC) {
         // CRC folds linearly: total = XOR over runs of crc_run * x^(8 * bytes after the run), all runs in parallel
         const uint64_t after = n - ((uint64_t)k1 * packet_size < n ? (uint64_t)k1 * packet_size : n);
-        a = len ? gf2_mulmod((uint32_t)a, gf2_xpow8(after)) : 0;
+        a = len ? gf2_mulmod(a, gf2_xpow8(after)) : 0;
     }
-    sa[t] = (uint32_t)a; sb[t] = (uint32_t)b; sl[t] = len;
+    sa[t] = a;
     __syncthreads();
-    if (kind == ZZ_CKS_CRC) {
-        for (uint32_t d = ZZ_RED_THREADS / 2; d >= 1; d >>= 1) {
-            if (t < d) sa[t] ^= sa[t + d];
-            __syncthreads();
-        }
-        if (t == 0) { out->a = sa[0]; out->b = 0; out->len = n; }
-        return;
+    for (uint32_t d = ZZ_RED_THREADS / 2; d >= 1; d >>= 1) {
+        if (t < d) sa[t] ^= sa[t + d];
+        __syncthreads();
     }
-    if (t == 0) {
-        uint64_t A = 0, B = 0, L = 0;
-        for (uint32_t i = 0; i < ZZ_RED_THREADS; ++i) {
-            if (sl[i] == 0) continue;
-            B = (B + sb[i] + (sl[i] % ZZ_ADLER_MOD) * A) % ZZ_ADLER_MOD;   // adler.cpp:5-15 combine
-            A = (A + sa[i]) % ZZ_ADLER_MOD;
-            L += sl[i];
-        }
-        out->a = (uint32_t)A; out->b = (uint32_t)B; out->len = L;
-    }
+    if (t == 0) { out->a = kind == ZZ_CKS_CRC ? sa[0] : 0; out->b = 0; out->len = n; }
 }
 
 }  // namespace zz

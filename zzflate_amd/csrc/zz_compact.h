@@ -15,30 +15,32 @@ struct zz_result {
 };
 
 #define ZZ_SCAN_THREADS 1024
-// exclusive prefix sum of sizes[0..npk) into offsets; total to res->stream_bytes. One workgroup.
+// exclusive prefix sum of sizes[0..npk) into offsets; total to res->stream_bytes. One workgroup, 4096 packets per
+// round: thread t takes four consecutive sizes (one 16-byte load), wave scan + scan of the 16 wave totals, running
+// carry between rounds.
 __global__ __launch_bounds__(ZZ_SCAN_THREADS) void k_scan_sizes(const uint32_t* sizes, uint32_t npk,
                                                                 uint64_t* offsets, zz_result* res)
 {
-    __shared__ uint64_t part[ZZ_SCAN_THREADS];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (npk + ZZ_SCAN_THREADS - 1) / ZZ_SCAN_THREADS;
-    uint32_t k0 = t * per, k1 = k0 + per;
-    if (k0 > npk) k0 = npk;
-    if (k1 > npk) k1 = npk;
-    uint64_t s = 0;
-    for (uint32_t k = k0; k < k1; ++k) s += sizes[k];
-    part[t] = s;
-    __syncthreads();
-    // Hillis-Steele over 1024 partials
-    for (uint32_t d = 1; d < ZZ_SCAN_THREADS; d <<= 1) {
-        uint64_t v = t >= d ? part[t - d] : 0;
+    __shared__ uint32_t wtot[ZZ_SCAN_THREADS / ZZ_WAVE];
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint64_t carry = 0;
+    for (uint32_t r0 = 0; r0 < npk; r0 += 4 * ZZ_SCAN_THREADS) {
+        const uint32_t k = r0 + 4 * t;
+        uint32_t v[4] = { 0, 0, 0, 0 };
+        if (k + 4 <= npk) { const uint4 q = *(const uint4*)(sizes + k); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else for (uint32_t i = 0; i < 4; ++i) if (k + i < npk) v[i] = sizes[k + i];
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];          // < 2^18 each: a round stays far below 2^32
+        const uint32_t incl = wave_scan_incl(mine);
+        if (lane == 63) wtot[wv] = incl;
         __syncthreads();
-        part[t] += v;
+        uint32_t wbase = 0, total = 0;
+        for (uint32_t i = 0; i < ZZ_SCAN_THREADS / ZZ_WAVE; ++i) { const uint32_t x = wtot[i]; if (i < wv) wbase += x; total += x; }
+        uint64_t o = carry + wbase + (incl - mine);
+        for (uint32_t i = 0; i < 4; ++i) { if (k + i < npk) offsets[k + i] = o; o += v[i]; }
+        carry += total;
         __syncthreads();
     }
-    uint64_t base = t ? part[t - 1] : 0;
-    for (uint32_t k = k0; k < k1; ++k) { offsets[k] = base; base += sizes[k]; }
-    if (t == ZZ_SCAN_THREADS - 1) res->stream_bytes = part[t];
+    if (t == 0) res->stream_bytes = carry;
 }
 
 // copy every packet's bytes from its slot to dst + offsets[k]; skipped entirely if the destination is too
