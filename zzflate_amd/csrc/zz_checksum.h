@@ -94,14 +94,20 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_adler_packets(zz_packet_params P)
 }
 
 // ---- CRC-32 per packet (sibling kernel; gzip container only) ------------------------------------------
-// 256 threads per packet; each thread runs slicing-by-4 over a contiguous slice from LDS tables, then the
-// packet CRC is the XOR over threads of crc_t * x^(8 * bytes after slice t).
+// 256 threads per packet, four wavefronts with a quarter of the packet each. Inside a quarter lane j takes the
+// 32-bit words j, j+64, j+128, ... so that every load is one coalesced 256-byte row. A lane's words sit 256 bytes
+// apart, so its Horner step is "times x^2048" instead of the usual "times x^32": the same four table lookups per
+// word as slicing-by-4 (crc.cpp:5-33 is the byte-wise form), with tables scaled by x^(8*252). The last word and
+// everything behind it (rest of the row, the later quarters) go into one GF(2) multiplication per lane; the
+// packet CRC is the XOR over lanes. CRC's initial value is folded into the packet's first word.
+// Packets that are not full (the last one) or not a multiple of 1024 bytes take the plain slicing-by-4 path.
 #define ZZ_CRC_THREADS 256
 __global__ __launch_bounds__(ZZ_CRC_THREADS) void k_crc32_packets(zz_packet_params P)
 {
-    __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t tab[4][256];      // slicing-by-4: (byte at register position k) * x^32
+    __shared__ uint32_t tabB[4][256];     // the same * x^(8*252): one step of 256 bytes
     __shared__ uint32_t red[ZZ_CRC_THREADS / ZZ_WAVE];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         uint32_t c = tid;
         for (int j = 0; j < 8; ++j) c = (c >> 1) ^ ((c & 1u) * ZZ_CRC_POLY);   // crc.cpp:5-20
@@ -113,7 +119,15 @@ __global__ __launch_bounds__(ZZ_CRC_THREADS) void k_crc32_packets(zz_packet_para
         tab[t][tid] = (c >> 8) ^ tab[0][c & 0xFF];
     }
     __syncthreads();
-    // x^(8 * bytes after my slice) for a full packet: the same for every full packet, so computed once
+    {
+        const uint32_t x252 = gf2_xpow8(252);
+        for (int t = 0; t < 4; ++t) tabB[t][tid] = gf2_mulmod(tab[t][tid], x252);
+    }
+    const bool fast = P.packet_size % 1024 == 0 && P.packet_size >= 1024;
+    const uint32_t quarter = P.packet_size / 4, rows = quarter / 256;
+    // fast path: x^(8 * bytes from my last word (inclusive of its own x^32) to the end of the packet)
+    const uint32_t ktail = gf2_xpow8(256 - 4 * lane + quarter * (3 - wv));
+    // slow path: x^(8 * bytes after my slice) for a full packet
     uint32_t shift_full;
     {
         const uint32_t len = P.packet_size;
@@ -122,34 +136,56 @@ __global__ __launch_bounds__(ZZ_CRC_THREADS) void k_crc32_packets(zz_packet_para
         if (b1 > len) b1 = len;
         shift_full = gf2_xpow8(len - b1);
     }
+    __syncthreads();
     for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
         const uint64_t off = (uint64_t)k * P.packet_size;
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
         const uint8_t* p = P.src + off;
-        const uint32_t slice = ((len + ZZ_CRC_THREADS - 1) / ZZ_CRC_THREADS + 3) & ~3u;
-        uint32_t b0 = tid * slice, b1 = b0 + slice;
-        if (b0 > len) b0 = len;
-        if (b1 > len) b1 = len;
         uint32_t c = 0;
-        if (b1 > b0) {
-            c = ~0u;
-            uint32_t i = b0;
-            for (; i + 4 <= b1; i += 4) {
-                c ^= load32(p + i);
-                c = tab[3][c & 0xFF] ^ tab[2][(c >> 8) & 0xFF] ^ tab[1][(c >> 16) & 0xFF] ^ tab[0][c >> 24];
+        if (fast && len == P.packet_size) {
+            const uint8_t* q = p + (uint64_t)wv * quarter + 4 * lane;
+            uint32_t s = (wv == 0 && lane == 0) ? ~0u : 0u;        // the initial value meets the first word
+            uint32_t r = 0;
+            for (; r + 8 < rows; r += 8) {
+                uint32_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = load32(q + (uint64_t)(r + u) * 256);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t v = s ^ w[u];
+                    s = tabB[3][v & 0xFF] ^ tabB[2][(v >> 8) & 0xFF] ^ tabB[1][(v >> 16) & 0xFF] ^ tabB[0][v >> 24];
+                }
             }
-            for (; i < b1; ++i) c = (c >> 8) ^ tab[0][(c & 0xFF) ^ p[i]];   // crc.cpp:28-31
-            c = ~c;
-            c = gf2_mulmod(c, len == P.packet_size ? shift_full : gf2_xpow8(len - b1));
+            for (; r + 1 < rows; ++r) {
+                const uint32_t v = s ^ load32(q + (uint64_t)r * 256);
+                s = tabB[3][v & 0xFF] ^ tabB[2][(v >> 8) & 0xFF] ^ tabB[1][(v >> 16) & 0xFF] ^ tabB[0][v >> 24];
+            }
+            c = gf2_mulmod(s ^ load32(q + (uint64_t)(rows - 1) * 256), ktail);
+        } else {
+            const uint32_t slice = ((len + ZZ_CRC_THREADS - 1) / ZZ_CRC_THREADS + 3) & ~3u;
+            uint32_t b0 = tid * slice, b1 = b0 + slice;
+            if (b0 > len) b0 = len;
+            if (b1 > len) b1 = len;
+            if (b1 > b0) {
+                c = ~0u;
+                uint32_t i = b0;
+                for (; i + 4 <= b1; i += 4) {
+                    c ^= load32(p + i);
+                    c = tab[3][c & 0xFF] ^ tab[2][(c >> 8) & 0xFF] ^ tab[1][(c >> 16) & 0xFF] ^ tab[0][c >> 24];
+                }
+                for (; i < b1; ++i) c = (c >> 8) ^ tab[0][(c & 0xFF) ^ p[i]];   // crc.cpp:28-31
+                c = ~c;
+                c = gf2_mulmod(c, len == P.packet_size ? shift_full : gf2_xpow8(len - b1));
+            }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) c ^= __shfl_xor(c, o);
-        if ((tid & 63) == 0) red[tid >> 6] = c;
+        if (lane == 0) red[wv] = c;
         __syncthreads();
         if (tid == 0) {
             uint32_t r = 0;
             for (int w = 0; w < ZZ_CRC_THREADS / ZZ_WAVE; ++w) r ^= red[w];
-            P.cks[k].a = r;
+            P.cks[k].a = (fast && len == P.packet_size) ? ~r : r;
             P.cks[k].b = 0;
         }
         __syncthreads();
