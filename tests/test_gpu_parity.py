@@ -91,7 +91,7 @@ def test_synthetic_edge_sizes(gpu, oracle, kind, lvl):
         got = gpu.encode(d, 0, lvl)
         assert got == oracle.encode_packets(d, 0, lvl), (kind, n, lvl)
         assert zlib.decompress(got) == d
-    for P in (1000, 4096, 32767):
+    for P in (1000, 1024, 2048, 4096, 32767):
         d = synth(kind, 70000, 2)
         assert gpu.encode(d, 1, lvl, P) == oracle.encode_packets(d, 1, lvl, P), (kind, P, lvl)
 

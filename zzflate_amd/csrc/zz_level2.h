@@ -36,7 +36,8 @@
 namespace zz {
 
 #define ZZ_L2_MAX_TOKENS 8192                       // every match covers >= 4 bytes of a <= 32768-byte packet
-// per resident workgroup: matches as len << 16 | dist (u32), records as u16 (literal byte | ZZ_L2_REC_MATCH)
+// per resident workgroup: matches as u32 (length symbol - 257 [27:23], length extra value [22:18], distance code
+// [17:13], distance extra value [12:0]), records as u16 (literal byte | ZZ_L2_REC_MATCH)
 #define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 4 + ZZ_MAX_PACKET * 2)
 #define ZZ_L2_REC_MATCH 0x100u
 #define ZZ_L2_REC_NONE 0x200u
@@ -460,20 +461,16 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
     return len < maxlen ? len : maxlen;
 }
 
-// One hop of the level-2 walk: a match at candidate lane e if it is strong and its lengths are exact, then e = the
-// first candidate at or after the next probe position.
+// One hop of the level-2 walk: a match at candidate lane e if it is "plain" (strong, lengths exact), then e = the
+// first candidate at or after the next probe position. winfo: fwd8 [4:0], need [7:5], "8 or more backward possible"
+// bit 8, "16 or more forward" bit 9, plain bit 10, strong bit 11, next candidate [22:16], lane + fwd8 [29:23].
 #define ZZ_L2_HOP \
                         "v_readlane_b32 %[inf], %[winfo], %[e]\n\t" \
-                        "s_bitcmp1_b64 %[S], %[e]\n\t" \
-                        "s_cbranch_scc0 6f\n\t"                     /* weak: look at the pending literals */ \
-                        "s_and_b32 %[t1], %[inf], 0x300\n\t"        /* "8 or more" backward possible | "16 or more" forward */ \
-                        "s_cmp_eq_u32 %[t1], 0\n\t" \
-                        "s_cbranch_scc0 4f\n\t" \
+                        "s_bitcmp1_b32 %[inf], 10\n\t" \
+                        "s_cbranch_scc0 5f\n\t"                     /* weak or flagged */ \
                         "s_bitset1_b64 %[ev], %[e]\n\t"             /* a match is found at this probe (:406-407) */ \
-                        "s_and_b32 %[t1], %[inf], 31\n\t" \
-                        "s_add_i32 %[Brel], %[e], %[t1]\n\t"        /* backRefEnd (:422), relative to the block */ \
-                        "s_add_u32 %[np], %[Brel], 1\n\t"           /* j = backRefEnd + 1 (:424) */ \
-                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"       /* hop: the first candidate at or after that */ \
+                        "s_bfe_u32 %[Brel], %[inf], 0x70017\n\t"    /* backRefEnd (:422), relative to the block */ \
+                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"       /* hop: the first candidate at or after j = backRefEnd + 1 (:424) */ \
                         "s_cmp_lt_u32 %[e], 64\n\t"
 
 // ---- token pass ------------------------------------------------------------------------------------------------
@@ -594,7 +591,9 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
             const bool weak = has && fwd8 < 4 && fwd8 + broom >= 4;
             const uint64_t Smask = ballot(strong);
             const uint64_t Amask = Smask | ballot(weak);
-            uint32_t winfo = fwd8 | ((weak ? 4 - fwd8 : 0) << 5) | (broom == 8 ? 0x100u : 0) | (fwd8 == 16 ? 0x200u : 0);
+            uint32_t winfo = fwd8 | ((weak ? 4 - fwd8 : 0) << 5) | (broom == 8 ? 0x100u : 0) | (fwd8 == 16 ? 0x200u : 0) |
+                             (strong ? 0x800u : 0) | (strong && broom != 8 && fwd8 != 16 ? 0x400u : 0) |
+                             (((uint32_t)lane + fwd8) << 23);
             {
                 const uint32_t endl = (uint32_t)lane + fwd8 + 1;                  // first lane probed after a match here
                 const uint64_t m = endl >= 64 ? 0 : (Amask & (~0ull << endl));
@@ -621,36 +620,35 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                         "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first candidate at or after np (-1: none)
                         "s_cmp_lt_i32 %[e], 0\n\t"
                         "s_cbranch_scc1 3f\n"
-                        // strong lanes without flags: two hops per taken branch (a taken branch costs about five
-                        // scalar instructions)
+                        // plain lanes: two hops per taken branch (a taken branch costs about five scalar instructions)
                         "9:\n\t"
-                        ZZ_L2_HOP "s_cbranch_scc0 3f\n\t"
-                        ZZ_L2_HOP "s_cbranch_scc1 9b\n\t"
+                        ZZ_L2_HOP "s_cbranch_scc0 10f\n\t"
+                        ZZ_L2_HOP "s_cbranch_scc1 9b\n"
+                        "10:\n\t"
+                        "s_add_u32 %[np], %[Brel], 1\n\t"           // no candidate left: j = backRefEnd + 1 (:424)
                         "s_branch 3f\n"
-                        // the same, entered half way: weak lanes that passed their test (7) and flagged lanes whose
-                        // lengths are exact after all (8)
+                        "5:\n\t"
+                        "s_bitcmp1_b32 %[inf], 11\n\t"
+                        "s_cbranch_scc1 4f\n\t"                     // strong but flagged
+                        "s_sub_i32 %[t1], %[e], %[Brel]\n\t"        // weak: pending literals j - backRefEnd (:404)
+                        "s_bfe_u32 %[t2], %[inf], 0x30005\n\t"
+                        "s_cmp_ge_i32 %[t1], %[t2]\n\t"
+                        "s_cbranch_scc1 7f\n\t"
+                        "s_add_u32 %[np], %[e], 1\n\t"              // no match at this probe: j++ (:430)
+                        "s_cmp_lt_u32 %[np], 64\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_branch 3f\n"
                         "7:\n\t"
                         "s_and_b32 %[t1], %[inf], 0x300\n\t"        // "8 or more" backward possible | "16 or more" forward
                         "s_cmp_eq_u32 %[t1], 0\n\t"
                         "s_cbranch_scc0 4f\n"
                         "8:\n\t"
                         "s_bitset1_b64 %[ev], %[e]\n\t"             // a match is found at this probe (:406-407)
-                        "s_and_b32 %[t1], %[inf], 31\n\t"
-                        "s_add_i32 %[Brel], %[e], %[t1]\n\t"        // backRefEnd (:422), relative to the block
-                        "s_add_u32 %[np], %[Brel], 1\n\t"           // j = backRefEnd + 1 (:424)
-                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"       // hop: the first candidate at or after that
+                        "s_bfe_u32 %[Brel], %[inf], 0x70017\n\t"
+                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"
                         "s_cmp_lt_u32 %[e], 64\n\t"
                         "s_cbranch_scc1 9b\n\t"
-                        "s_branch 3f\n"
-                        "6:\n\t"
-                        "s_sub_i32 %[t1], %[e], %[Brel]\n\t"        // pending literals j - backRefEnd (:404)
-                        "s_bfe_u32 %[t2], %[inf], 0x30005\n\t"
-                        "s_cmp_ge_i32 %[t1], %[t2]\n\t"
-                        "s_cbranch_scc1 7b\n\t"
-                        "s_add_u32 %[np], %[e], 1\n\t"              // no match at this probe: j++ (:430)
-                        "s_cmp_lt_u32 %[np], 64\n\t"
-                        "s_cbranch_scc1 1b\n\t"
-                        "s_branch 3f\n"
+                        "s_branch 10b\n"
                         "4:\n\t"
                         "s_bitcmp1_b32 %[inf], 9\n\t"
                         "s_cbranch_scc1 2f\n\t"                     // forward "16 or more": extend in C++
@@ -663,7 +661,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                         "3:\n\t"
                         : [Brel] "+s"(Brel), [np] "+s"(np), [ev] "+s"(evmask), [slow] "+s"(slow), [inf] "=&s"(inf),
                           [t1] "=&s"(t1), [t2] "=&s"(t2), [tmp] "=&s"(tmp), [e] "=&s"(e)
-                        : [winfo] "v"(winfo), [S] "s"(Smask), [A] "s"(Amask)
+                        : [winfo] "v"(winfo), [A] "s"(Amask)
                         : "scc");
                 }
                 B = base + (uint32_t)Brel;
@@ -711,7 +709,11 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                 const bool ev = (evmask >> lane) & 1;
                 if (ev) {
                     const uint32_t ms = tk & 0xFFFF, mlen = tk >> 16, dist = q - c;
-                    tokens[ntok + mbcnt(evmask)] = (mlen << 16) | dist;
+                    uint32_t sym, leb, lev, bucket, deb, dev;            // GetFrequencies, :455-463
+                    length_symbol(mlen, sym, leb, lev);
+                    dist_symbol(dist, bucket, deb, dev);
+                    // the match as the emission pass wants it: symbols and extra-bit values (ZZ_L2_TOK_*)
+                    tokens[ntok + mbcnt(evmask)] = ((sym - 257) << 23) | (lev << 18) | (bucket << 13) | dev;
                     // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
                     const uint32_t last = ms + mlen - 1;
                     for (uint32_t wi = ms >> 6; wi <= (last >> 6); ++wi) {
@@ -721,10 +723,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                         atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], (unsigned long long)mask);
                     }
                     atomicOr((unsigned long long*)&mstw[(ms >> 6) & (ZZ_L2_WIN - 1)], 1ull << (ms & 63));
-                    uint32_t sym, eb, evv, bucket;                       // GetFrequencies, :455-463
-                    length_symbol(mlen, sym, eb, evv);
                     hist_add(histP, sym);
-                    dist_symbol(dist, bucket, eb, evv);
                     hist_add(histP, 286 + bucket);
                 }
                 ntok += (uint32_t)__builtin_popcountll(evmask);
@@ -923,29 +922,35 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
                 }
                 ring_append(ring, bits, nb);
             }
-            // body: WriteRecords (:149-169), 64 records per trip; the next trip's records are already in flight
+            // body: WriteRecords (:149-169), 64 records per trip. Loads run ahead of their use: records by two
+            // trips, the matches a trip needs (a gather, their index depends on the records) by one.
             {
+                const uint32_t dummy = 0;
                 uint32_t mc = 0;
                 uint32_t v = (uint32_t)lane < nbody ? recs[lane] : ZZ_L2_REC_NONE;
+                uint32_t vn = 64u + (uint32_t)lane < nbody ? recs[64 + lane] : ZZ_L2_REC_NONE;
+                uint64_t mb = ballot(v == ZZ_L2_REC_MATCH);
+                uint32_t t = dummy;
+                if (v == ZZ_L2_REC_MATCH) t = tokens[mbcnt(mb)];
                 for (uint32_t r0 = 0; r0 < nbody; r0 += 64) {
-                    const uint32_t rn = r0 + 64 + (uint32_t)lane;
-                    const uint32_t vn = rn < nbody ? recs[rn] : ZZ_L2_REC_NONE;
-                    const bool ism = v == ZZ_L2_REC_MATCH;
-                    const uint64_t mb = ballot(ism);
-                    uint32_t t = (3u << 16) | 1u;
-                    if (ism) t = tokens[mc + mbcnt(mb)];
+                    const uint32_t rnn = r0 + 128 + (uint32_t)lane;
+                    const uint32_t vnn = rnn < nbody ? recs[rnn] : ZZ_L2_REC_NONE;
+                    mc += (uint32_t)__builtin_popcountll(mb);
+                    const uint64_t mbn = ballot(vn == ZZ_L2_REC_MATCH);
+                    uint32_t tn = dummy;
+                    if (vn == ZZ_L2_REC_MATCH) tn = tokens[mc + mbcnt(mbn)];
                     uint64_t bits = 0; uint32_t nb = 0;
                     if (v < ZZ_L2_REC_MATCH) {
                         const uint32_t cd = codes[v];
                         bits = cd & 0xFFFF; nb = cd >> 16;
-                    } else if (ism) {
-                        uint32_t sym, eb, ev, bucket, deb, dev;
-                        length_symbol(t >> 16, sym, eb, ev);
-                        const uint32_t lc = codes[sym];
+                    } else if (v == ZZ_L2_REC_MATCH) {
+                        const uint32_t ls = t >> 23, lev = (t >> 18) & 31, bucket = (t >> 13) & 31, dev = t & 0x1FFF;
+                        const uint32_t leb = (ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2;      // luts.cpp:64
+                        const uint32_t deb = bucket < 4 ? 0 : (bucket - 2) >> 1;
+                        const uint32_t lc = codes[257 + ls];
                         uint32_t ln = lc >> 16;
-                        uint64_t w = (lc & 0xFFFF) | ((uint64_t)ev << ln);          // Merge, :121-124
-                        ln += eb;
-                        dist_symbol(t & 0xFFFF, bucket, deb, dev);
+                        uint64_t w = (lc & 0xFFFF) | ((uint64_t)lev << ln);         // Merge, :121-124
+                        ln += leb;
                         const uint32_t dc = dcodes[bucket];
                         w |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
                         ln += dc >> 16;
@@ -954,8 +959,7 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
                         bits = w; nb = ln;
                     }
                     ring_append64(ring, bits, nb);
-                    mc += (uint32_t)__builtin_popcountll(mb);
-                    v = vn;
+                    v = vn; vn = vnn; t = tn; mb = mbn;
                 }
             }
             {   // codes[256] (:300)
