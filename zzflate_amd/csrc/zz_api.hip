@@ -232,7 +232,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         } else if (level == 1) {
             // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-            hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_WAVE), pad_lds, st, pp);
+            hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
         } else {
             launch_level2(pp, c->l2_scratch, st);
         }
