@@ -476,17 +476,29 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
 // ---- token pass ------------------------------------------------------------------------------------------------
 // FirstPass + AddHashEntries over the whole packet (encoder.cpp:217-248, 375-440, 474-480). Returns the number
 // of matches written to `tokens` (ascending start) and, through nrec_out, the number of records in `recs`.
+// Hand-over from the parsing wavefront to the helper wavefront, one slot per 64-position block, two slots:
+// word l = lane l's match (ZZ_L2_HB_*), words 64,65 = mask of lanes that found one. The helper picks a slot up behind
+// barrier i; the parser overwrites it after barrier i + 1.
+#define ZZ_L2_HB_WORDS 66u
+#define ZZ_L2_HB_PACK(ms, mlen, dist, base) (((ms) + 258u - (base)) | (((mlen) - 3u) << 9) | ((dist) << 17))
+__device__ __forceinline__ void l2_block_barrier()
+{
+    // this wave's LDS traffic must have landed; its global loads (prefetches) stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ uint32_t l2_probe_blocks(uint32_t n)     // trips of the token pass = hand-over barriers
+{
+    const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;
+    return (target + 63) >> 6;
+}
+
 template <bool SAFE>
-__device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
-                                                  uint32_t* tokens, uint16_t* recs, const uint8_t* src,
-                                                  const uint8_t* end, uint32_t n, uint64_t before, uint32_t& nrec_out,
-                                                  unsigned long long* prof = nullptr)
+__device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const uint8_t* src, const uint8_t* end,
+                                              uint32_t n, uint64_t before, unsigned long long* prof = nullptr)
 {
     const int lane = lane_id();
     ZZ_PROF_DECL
-    uint32_t nrec = 0, Fnext = 0;
     const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
-    uint32_t ntok = 0;
     uint32_t B = 1;                 // backRefEnd (:380)
     uint32_t nextProbe = 1;         // j (:383)
     uint32_t batchEnd = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
@@ -510,9 +522,6 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         }
         ZZ_T(6);
         const uint32_t q = base + lane;
-        // the block that becomes final in this trip: its bytes are fetched now, used at the bottom
-        uint32_t fbyte = 0;
-        if (base >= 64 * ZZ_L2_LAG) fbyte = src[q - 64 * ZZ_L2_LAG];
         const bool ins = q < n && q != skipPos && q != 0;
         const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
         const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
@@ -531,6 +540,7 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
             ld128<SAFE>(src + q + 64, end, wan, wan2);
             wbn = load64(src + q + 56);
         }
+        if (base) l2_block_barrier();     // releases the previous block's matches to the helper (the table read above had to land anyway)
         ZZ_WAVE_SYNC();
         // Positions of this block that share a hash: the read-back names the lane whose store landed, the same
         // lane for every member of a set and a different one for different sets -- a 6-bit key. Six ballots give
@@ -704,40 +714,70 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
                 }
             }
             ZZ_T(9);
-            // ---- publish this block's tokens and their bitmap bits, all event lanes at once ----------------
-            if (evmask) {
-                const bool ev = (evmask >> lane) & 1;
-                if (ev) {
-                    const uint32_t ms = tk & 0xFFFF, mlen = tk >> 16, dist = q - c;
-                    uint32_t sym, leb, lev, bucket, deb, dev;            // GetFrequencies, :455-463
-                    length_symbol(mlen, sym, leb, lev);
-                    dist_symbol(dist, bucket, deb, dev);
-                    // the match as the emission pass wants it: symbols and extra-bit values (ZZ_L2_TOK_*)
-                    tokens[ntok + mbcnt(evmask)] = ((sym - 257) << 23) | (lev << 18) | (bucket << 13) | dev;
-                    // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
-                    const uint32_t last = ms + mlen - 1;
-                    for (uint32_t wi = ms >> 6; wi <= (last >> 6); ++wi) {
-                        const uint32_t lo = wi == (ms >> 6) ? (ms & 63) : 0;
-                        const uint32_t hi = wi == (last >> 6) ? (last & 63) : 63;
-                        const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
-                        atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], (unsigned long long)mask);
-                    }
-                    atomicOr((unsigned long long*)&mstw[(ms >> 6) & (ZZ_L2_WIN - 1)], 1ull << (ms & 63));
-                    hist_add(histP, sym);
-                    hist_add(histP, 286 + bucket);
-                }
-                ntok += (uint32_t)__builtin_popcountll(evmask);
-            }
+            // ---- hand this block's matches to the helper wavefront ------------------------------------------------
+            uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
+            if ((evmask >> lane) & 1) slot[lane] = ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, q - c, base);
+            if (lane == 0) { slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32); }
+        } else if (lane == 0) {
+            uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
+            slot[64] = 0; slot[65] = 0;
         }
         ZZ_T(12);
+        wa = wan; wa2 = wan2; wb = wbn;
+    }
+    if (target) l2_block_barrier();       // the last block's matches
+#ifdef ZZ_PROF
+    if (lane == 0 && prof) { for (int _i = 6; _i < 10; ++_i) atomicAdd(&prof[_i], prof_acc[_i]); atomicAdd(&prof[12], prof_acc[12]); }
+#endif
+}
+
+// The helper wavefront's side of the token pass: per block, publish the parser's matches (scratch, bitmap window,
+// symbol counts) and finish the block that can no longer change. Returns the number of matches; the number of
+// records through nrec_out.
+__device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
+                                                   uint32_t* tokens, uint16_t* recs, const uint8_t* src, uint32_t n,
+                                                   uint32_t& nrec_out)
+{
+    const int lane = lane_id();
+    const uint32_t trips = l2_probe_blocks(n);
+    uint32_t nrec = 0, Fnext = 0, ntok = 0;
+    for (uint32_t i = 0; i < trips; ++i) {
+        const uint32_t base = i << 6;
+        // the block that becomes final in this trip: its bytes are fetched before the wait
+        uint32_t fbyte = 0;
+        if (i >= ZZ_L2_LAG) fbyte = src[base + lane - 64 * ZZ_L2_LAG];
+        l2_block_barrier();
+        const uint32_t* slot = hb + (i & 1) * ZZ_L2_HB_WORDS;
+        const uint32_t pk = slot[lane];
+        const uint64_t evmask = ((uint64_t)uniform(slot[65]) << 32) | uniform(slot[64]);
+        if (evmask) {
+            if ((evmask >> lane) & 1) {
+                const uint32_t ms = base + (pk & 0x1FF) - 258u, mlen = ((pk >> 9) & 0xFF) + 3u, dist = pk >> 17;
+                uint32_t sym, leb, lev, bucket, deb, dev;            // GetFrequencies, :455-463
+                length_symbol(mlen, sym, leb, lev);
+                dist_symbol(dist, bucket, deb, dev);
+                // the match as the emission pass wants it: symbols and extra-bit values
+                tokens[ntok + mbcnt(evmask)] = ((sym - 257) << 23) | (lev << 18) | (bucket << 13) | dev;
+                // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
+                const uint32_t last = ms + mlen - 1;
+                for (uint32_t wi = ms >> 6; wi <= (last >> 6); ++wi) {
+                    const uint32_t lo = wi == (ms >> 6) ? (ms & 63) : 0;
+                    const uint32_t hi = wi == (last >> 6) ? (last & 63) : 63;
+                    const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
+                    atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], (unsigned long long)mask);
+                }
+                atomicOr((unsigned long long*)&mstw[(ms >> 6) & (ZZ_L2_WIN - 1)], 1ull << (ms & 63));
+                hist_add(histP, sym);
+                hist_add(histP, 286 + bucket);
+            }
+            ntok += (uint32_t)__builtin_popcountll(evmask);
+        }
         // later matches start at >= base + 64 - 258: block (base>>6) - 5 cannot change any more
-        if (base >= 64 * ZZ_L2_LAG) {
+        if (i >= ZZ_L2_LAG) {
             ZZ_WAVE_SYNC();
             nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, fbyte);
             Fnext++;
         }
-        ZZ_T(13);
-        wa = wan; wa2 = wan2; wb = wbn;
     }
     ZZ_WAVE_SYNC();
     for (const uint32_t nblk = (n + 63) >> 6; Fnext < nblk; ++Fnext) {       // the tail nobody probes (:222) + the lag
@@ -745,9 +785,6 @@ __device__ __forceinline__ uint32_t l2_token_pass(uint16_t* T, uint64_t* covw, u
         nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, p < n ? src[p] : 0u);
     }
     nrec_out = nrec;
-#ifdef ZZ_PROF
-    if (lane == 0 && prof) { for (int _i = 6; _i < 10; ++_i) atomicAdd(&prof[_i], prof_acc[_i]); atomicAdd(&prof[12], prof_acc[12]); atomicAdd(&prof[13], prof_acc[13]); }
-#endif
     return ntok;
 }
 
@@ -756,14 +793,22 @@ struct zz_l2_params {
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
 };
 
-#define ZZ_L2_LDS_BYTES (16384 + 512 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
+#define ZZ_L2_LDS_BYTES (16384 + 528 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
+#define ZZ_L2_THREADS (2 * ZZ_WAVE)
+// one wave's own memory traffic has landed (the code after the token pass runs on wavefront 0 alone: no s_barrier there)
+#define ZZ_WAVE_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 
-__global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
+// Two wavefronts per packet. During the token pass wavefront 0 parses (hash table, candidates, the serial walk) and
+// wavefront 1 keeps the books (matches to scratch, bitmap window, symbol counts, finished blocks to records), one
+// s_barrier per 64-position block. Afterwards wavefront 0 builds the codes and emits while wavefront 1 computes the
+// packet's Adler-32.
+__global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
-    // ---- LDS carve-up: 17,792 bytes => nine workgroups per CU (with <= 168 VGPRs: three waves per SIMD). The hash
-    // table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the code tables
-    // all live inside it; only the bit ring, the bitmap window and the packed counters need their own space.
+    // ---- LDS carve-up: 17,808 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
+    // The hash table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the
+    // code tables all live inside it; the bit ring (used after the token pass) shares its space with the
+    // hand-over slots (used during it); the bitmap window and the packed counters have their own.
     __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES];
     uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table during the token pass
     uint32_t* symF = (uint32_t*)(lds + 8192);                     // 1280: 286 lit/len + pad | 30 dist at [288..318)
@@ -772,10 +817,11 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
     uint32_t* dcodes = (uint32_t*)(lds + 8192 + 1280 + 1152);     // 128: 30 distance codes
     uint32_t* metaF = (uint32_t*)(lds + 8192 + 1280 + 1152 + 128);            // 80: 19 meta frequencies
     uint32_t* misc = (uint32_t*)(lds + 11264);                    // 256: lane-0 results [0..3], code-generation work area [16..48)
-    uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512
-    uint64_t* covw = (uint64_t*)(lds + 16384 + 512);              // 128: covered bits of the 16 blocks around the probe front
+    uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512 (+16 pad)
+    uint32_t* hb = (uint32_t*)(lds + 16384);                      // 528: two hand-over slots, same bytes as the ring
+    uint64_t* covw = (uint64_t*)(lds + 16384 + 528);              // 128: covered bits of the 16 blocks around the probe front
     uint64_t* mstw = covw + ZZ_L2_WIN;                            // 128: match-start bits
-    uint32_t* histP = (uint32_t*)(lds + 16384 + 512 + 2 * ZZ_L2_WIN * 8);     // 640: packed 16-bit counters
+    uint32_t* histP = (uint32_t*)(lds + 16384 + 528 + 2 * ZZ_L2_WIN * 8);     // 640: packed 16-bit counters
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -790,6 +836,7 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
     uint16_t* rle = (uint16_t*)(lds + 7344);       // up to 316+30 records -> 704 bytes
 
     const int lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x >> 6);
     ZZ_PROF_DECL
     uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES;
     uint32_t* tokens = (uint32_t*)my_scratch;                                   // matches in stream order
@@ -805,30 +852,43 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
         const uint64_t before = P.halo + off;            // input bytes in front of the packet (D4: stop at 0)
         uint8_t* out = P.slots + (uint64_t)k * P.slot_stride;
 
-        __syncthreads();
-        {
+        __syncthreads();       // both wavefronts are done with the previous packet
+        if (wave == 0) {
             uint4* z = (uint4*)lds;
             for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
+        } else {
             uint32_t* zw = (uint32_t*)covw;
             for (int i = lane; i < 2 * ZZ_L2_WIN * 2 + ZZ_L2_HIST_WORDS; i += ZZ_WAVE) zw[i] = 0;   // window + counters
         }
-        bitring ring;
-        ring_init(ring, ring_words, out);
-
-        if (P.cks_kind == ZZ_CKS_ADLER) {
-            zz_cks c = wave_adler(src, len);
-            if (lane == 0) P.cks[k] = c;
-        }
+        ZZ_WAVE_SYNC();
         ZZ_T(0);
 
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
-            // loads may run a few bytes past the packet: only the last two packets can leave the buffer that way
-            uint32_t nbody = 0;      // records of the block body (literals + matches)
-            const uint32_t ntok = k + 2 >= P.npk
-                ? l2_token_pass<true>(T, covw, mstw, histP, tokens, recs, src, end, n, before, nbody, P.prof)
-                : l2_token_pass<false>(T, covw, mstw, histP, tokens, recs, src, end, n, before, nbody, P.prof);
-            __syncthreads();   // token / record stores (global) are read back by other lanes below
+            if (wave == 0) {
+                // loads may run a few bytes past the packet: only the last two packets can leave the buffer that way
+                if (k + 2 >= P.npk) l2_token_pass<true>(T, hb, src, end, n, before, P.prof);
+                else l2_token_pass<false>(T, hb, src, end, n, before, P.prof);
+            } else {
+                uint32_t nb = 0;
+                const uint32_t nt = l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb);
+                if (lane == 0) { covw[0] = ((uint64_t)nt << 32) | nb; }       // the window is dead now
+            }
+            __syncthreads();   // counts, window and the helper's global stores are complete
+        }
+        if (wave != 0) {
+            // the helper's last job: the checksum, while wavefront 0 builds codes and emits
+            if (P.cks_kind == ZZ_CKS_ADLER) {
+                zz_cks c = wave_adler(src, len);
+                if (lane == 0) P.cks[k] = c;
+            }
+            continue;
+        }
+        // ---- wavefront 0 alone from here to the end of the packet ------------------------------------------------
+        bitring ring;
+        ring_init(ring, ring_words, out);
+        if (n > 0) {
+            const uint32_t nbody = (uint32_t)covw[0], ntok = (uint32_t)(covw[0] >> 32);   // records (literals + matches), matches
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this scratch held the previous packet's records: drop stale L1 lines
             // the hash table is dead now: its space is reused. Unpack the counters (GetFrequencies, :442-471).
             for (int i = lane; i < 320; i += ZZ_WAVE) {
@@ -839,7 +899,7 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
             }
             if (lane < 20) metaF[lane] = 0;
             ZZ_T(1); ZZ_C(10, 1); ZZ_C(11, ntok);
-            __syncthreads();
+            ZZ_WAVE_SYNC();
 
             ZZ_T(2);
             // ================= code construction =================================================================
@@ -870,7 +930,7 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
             }
             const uint32_t total = 3 + 5 + 5 + 4 + 3 * 19 + wave_sum(bitsum);    // :267
             const uint32_t required = (total + 8) / 8;                           // requiredLength, :271
-            __syncthreads();
+            ZZ_WAVE_SYNC();
             ZZ_T(3);
 
             if (required >= n) {
@@ -882,7 +942,7 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
                     out[3] = (uint8_t)~n; out[4] = (uint8_t)(~n >> 8);
                 }
                 coop_copy(out + 5, src, n, lane, ZZ_WAVE);
-                __syncthreads();
+                ZZ_WAVE_DRAIN();
                 uint32_t bytes = 5 + n;
                 if (!is_final) {
                     if (lane == 0) {
@@ -899,7 +959,7 @@ __global__ __launch_bounds__(ZZ_WAVE, 3) void k_encode_l2(zz_l2_params Q)
             generate_codes_w(lens, 286, codes, misc + 16);                        // huffman::generate
             generate_codes_w(lens + 288, 30, dcodes, misc + 16);
             generate_codes_w(metaLens, 19, metaCodes, misc + 16);
-            __syncthreads();
+            ZZ_WAVE_SYNC();
             ZZ_T(4);
             // StartBlock(UserDefinedHuffman, final) + HLIT=29 HDIST=29 HCLEN=15 (:280-285)
             ring_append_uniform(ring, (is_final ? 1u : 0u) | (2u << 1) | (29u << 3) | (29u << 8) | (15u << 13), 17);
@@ -995,7 +1055,7 @@ static inline uint32_t l2_grid(uint32_t npk)
 static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, hipStream_t st)
 {
     zz_l2_params q; q.pk = pp; q.scratch = scratch;
-    hipLaunchKernelGGL(k_encode_l2, dim3(l2_grid(pp.npk)), dim3(ZZ_WAVE), 0, st, q);
+    hipLaunchKernelGGL(k_encode_l2, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
 }
 
 }  // namespace zz
