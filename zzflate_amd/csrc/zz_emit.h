@@ -17,6 +17,8 @@ struct bitring {
     uint32_t* out32;     // destination (4-byte aligned)
     uint32_t bitpos;     // bits appended so far
     uint32_t flushed;    // whole words already stored to out32
+    uint32_t hold;       // level 2, second emitter: this word goes to *holdp instead of out32 (~0u: none)
+    uint32_t* holdp;
 };
 
 __device__ __forceinline__ void ring_init(bitring& r, uint32_t* lds_ring, uint8_t* out)
@@ -25,6 +27,8 @@ __device__ __forceinline__ void ring_init(bitring& r, uint32_t* lds_ring, uint8_
     r.out32 = (uint32_t*)out;
     r.bitpos = 0;
     r.flushed = 0;
+    r.hold = ~0u;
+    r.holdp = nullptr;
     for (int i = lane_id(); i < ZZ_RING_WORDS; i += ZZ_WAVE) lds_ring[i] = 0;
     ZZ_WAVE_SYNC();
 }

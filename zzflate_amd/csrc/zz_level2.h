@@ -80,11 +80,21 @@ __device__ __forceinline__ void ring_flush_all_full(bitring& r)
         if (w < upto) {
             uint32_t v = r.ring[w & (ZZ_RING_WORDS - 1)];
             r.ring[w & (ZZ_RING_WORDS - 1)] = 0;
-            r.out32[w] = v;
+            if (w == r.hold) *r.holdp = v;      // shared with the other emitter's last word: merged at the end
+            else r.out32[w] = v;
         }
         r.flushed = upto;
         ZZ_WAVE_SYNC();
     }
+}
+// a ring that continues a bit stream at bit `bitpos`; its first word is held back (see bitring::hold)
+__device__ __forceinline__ void ring_init_at(bitring& r, uint32_t* lds_ring, uint8_t* out, uint32_t bitpos, uint32_t* holdp)
+{
+    ring_init(r, lds_ring, out);
+    r.bitpos = bitpos;
+    r.flushed = bitpos >> 5;
+    r.hold = bitpos >> 5;
+    r.holdp = holdp;
 }
 // every lane appends nb <= 48 bits (so one append adds at most 96 words; the ring holds 128)
 __device__ __forceinline__ void ring_append64(bitring& r, uint64_t bits, uint32_t nb)
@@ -105,6 +115,26 @@ __device__ __forceinline__ void ring_append64(bitring& r, uint64_t bits, uint32_
     }
     r.bitpos += total;
     ring_flush_all_full(r);
+}
+
+__device__ __forceinline__ void ring_append_uniform64(bitring& r, uint32_t bits, uint32_t nb)   // hold-aware twin of ring_append_uniform
+{
+    ring_append64(r, lane_id() == 0 ? bits : 0u, lane_id() == 0 ? nb : 0u);
+}
+// ring_finish for a ring that may still hold its first word back
+__device__ __forceinline__ uint32_t ring_finish_hold(bitring& r)
+{
+    ring_pad_to_byte(r);
+    const uint32_t bytes = r.bitpos >> 3;
+    const uint32_t words = (bytes + 3) >> 2;
+    ZZ_WAVE_SYNC();
+    const uint32_t w = r.flushed + lane_id();
+    if (w < words) {
+        const uint32_t v = r.ring[w & (ZZ_RING_WORDS - 1)];
+        if (w == r.hold) *r.holdp = v;
+        else r.out32[w] = v;
+    }
+    return bytes;
 }
 
 // ---- Huffman code construction (lane 0, LDS scratch) ---------------------------------------------------------
@@ -788,6 +818,79 @@ __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t*
     return ntok;
 }
 
+// ---- block body: WriteRecords (encoder.cpp:149-169) over the dense records [r_begin, r_end), 64 per trip --------
+// Loads run ahead of their use: records by two trips, the matches a trip needs (a gather: their index depends on
+// the records) by one. `mc` = number of matches in front of r_begin.
+__device__ __forceinline__ void l2_emit_records(bitring& ring, const uint16_t* recs, const uint32_t* tokens,
+                                                const uint32_t* codes, const uint32_t* dcodes, uint32_t r_begin,
+                                                uint32_t r_end, uint32_t mc)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t v = r_begin + lane < r_end ? recs[r_begin + lane] : ZZ_L2_REC_NONE;
+    uint32_t vn = r_begin + 64 + lane < r_end ? recs[r_begin + 64 + lane] : ZZ_L2_REC_NONE;
+    uint64_t mb = ballot(v == ZZ_L2_REC_MATCH);
+    uint32_t t = 0;
+    if (v == ZZ_L2_REC_MATCH) t = tokens[mc + mbcnt(mb)];
+    for (uint32_t r0 = r_begin; r0 < r_end; r0 += 64) {
+        const uint32_t rnn = r0 + 128 + lane;
+        const uint32_t vnn = rnn < r_end ? recs[rnn] : ZZ_L2_REC_NONE;
+        mc += (uint32_t)__builtin_popcountll(mb);
+        const uint64_t mbn = ballot(vn == ZZ_L2_REC_MATCH);
+        uint32_t tn = 0;
+        if (vn == ZZ_L2_REC_MATCH) tn = tokens[mc + mbcnt(mbn)];
+        uint64_t bits = 0; uint32_t nb = 0;
+        if (v < ZZ_L2_REC_MATCH) {
+            const uint32_t cd = codes[v];
+            bits = cd & 0xFFFF; nb = cd >> 16;
+        } else if (v == ZZ_L2_REC_MATCH) {
+            const uint32_t ls = t >> 23, lev = (t >> 18) & 31, bucket = (t >> 13) & 31, dev = t & 0x1FFF;
+            const uint32_t leb = (ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2;      // luts.cpp:64
+            const uint32_t deb = bucket < 4 ? 0 : (bucket - 2) >> 1;
+            const uint32_t lc = codes[257 + ls];
+            uint32_t ln = lc >> 16;
+            uint64_t w = (lc & 0xFFFF) | ((uint64_t)lev << ln);         // Merge, :121-124
+            ln += leb;
+            const uint32_t dc = dcodes[bucket];
+            w |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
+            ln += dc >> 16;
+            w |= (uint64_t)dev << ln;
+            ln += deb;
+            bits = w; nb = ln;
+        }
+        ring_append64(ring, bits, nb);
+        v = vn; vn = vnn; t = tn; mb = mbn;
+    }
+}
+// the same walk without output: bits the records [0, r_end) will take, and how many of them are matches
+__device__ __forceinline__ uint32_t l2_count_bits(const uint16_t* recs, const uint32_t* tokens, const uint32_t* codes,
+                                                  const uint32_t* dcodes, uint32_t r_end, uint32_t& matches)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t mc = 0, acc = 0;
+    uint32_t v = lane < r_end ? recs[lane] : ZZ_L2_REC_NONE;
+    uint32_t vn = 64 + lane < r_end ? recs[64 + lane] : ZZ_L2_REC_NONE;
+    uint64_t mb = ballot(v == ZZ_L2_REC_MATCH);
+    uint32_t t = 0;
+    if (v == ZZ_L2_REC_MATCH) t = tokens[mbcnt(mb)];
+    for (uint32_t r0 = 0; r0 < r_end; r0 += 64) {
+        const uint32_t rnn = r0 + 128 + lane;
+        const uint32_t vnn = rnn < r_end ? recs[rnn] : ZZ_L2_REC_NONE;
+        mc += (uint32_t)__builtin_popcountll(mb);
+        const uint64_t mbn = ballot(vn == ZZ_L2_REC_MATCH);
+        uint32_t tn = 0;
+        if (vn == ZZ_L2_REC_MATCH) tn = tokens[mc + mbcnt(mbn)];
+        if (v < ZZ_L2_REC_MATCH) acc += codes[v] >> 16;
+        else if (v == ZZ_L2_REC_MATCH) {
+            const uint32_t ls = t >> 23, bucket = (t >> 13) & 31;
+            acc += (codes[257 + ls] >> 16) + ((ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2) + (dcodes[bucket] >> 16) +
+                   (bucket < 4 ? 0 : (bucket - 2) >> 1);
+        }
+        v = vn; vn = vnn; t = tn; mb = mbn;
+    }
+    matches = mc;
+    return wave_sum(acc);
+}
+
 struct zz_l2_params {
     zz_packet_params pk;
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
@@ -876,11 +979,44 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
             }
             __syncthreads();   // counts, window and the helper's global stores are complete
         }
+        uint32_t* share = misc + 4;      // [0] 1 stored / 2 dynamic, [1] first record of the helper's part, [2] bits in front of
+                                         // the records, [3] wavefront 0's last (partial) word, [4] the helper's first word
         if (wave != 0) {
-            // the helper's last job: the checksum, while wavefront 0 builds codes and emits
+            // the checksum while wavefront 0 builds the codes ...
             if (P.cks_kind == ZZ_CKS_ADLER) {
                 zz_cks c = wave_adler(src, len);
                 if (lane == 0) P.cks[k] = c;
+            }
+            if (n > 0) {
+                __syncthreads();             // (X) codes are ready, or the block went out stored
+                if (uniform(share[0]) == 2) {
+                    // ... then the second part of the records, the end of the block and the end of the packet. Its
+                    // place in the bit stream follows from a dry run over the first part.
+                    const uint32_t nbody = (uint32_t)covw[0], r1 = uniform(share[1]);
+                    uint32_t m1 = 0;
+                    const uint32_t bits1 = l2_count_bits(recs, tokens, codes, dcodes, r1, m1);
+                    bitring ring2;
+                    ring_init_at(ring2, (uint32_t*)(lds + 11520), out, uniform(share[2]) + bits1, share + 4);
+                    l2_emit_records(ring2, recs, tokens, codes, dcodes, r1, nbody, m1);
+                    {   // codes[256] (:300)
+                        const uint32_t cd = codes[256];
+                        ring_append_uniform64(ring2, cd & 0xFFFF, cd >> 16);
+                    }
+                    if (!is_final) {
+                        // one stored byte = byte alignment (zzflate.cpp:118-120)
+                        ring_append_uniform64(ring2, 0, 3);
+                        ring_pad_to_byte(ring2);
+                        ring_append_uniform64(ring2, 0xFFFE0001u, 32);
+                        ring_append_uniform64(ring2, src[len - 1], 8);
+                    }
+                    const uint32_t bytes = ring_finish_hold(ring2);
+                    __syncthreads();         // (Y) wavefront 0's last word is in share[3]
+                    if (lane == 0) {
+                        ring2.out32[ring2.hold] = share[4] | share[3];
+                        P.sizes[k] = bytes;
+                        if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+                    }
+                }
             }
             continue;
         }
@@ -951,7 +1087,8 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
                     }
                     bytes += 6;
                 }
-                if (lane == 0) P.sizes[k] = bytes;
+                if (lane == 0) { P.sizes[k] = bytes; share[0] = 1; }
+                __syncthreads();             // (X)
                 continue;
             }
 
@@ -982,49 +1119,18 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
                 }
                 ring_append(ring, bits, nb);
             }
-            // body: WriteRecords (:149-169), 64 records per trip. Loads run ahead of their use: records by two
-            // trips, the matches a trip needs (a gather, their index depends on the records) by one.
+            // body: both wavefronts emit. This one takes the records [0, r1), the helper the rest and everything behind
+            // them; the word the two parts share is put together by the helper at the end.
             {
-                const uint32_t dummy = 0;
-                uint32_t mc = 0;
-                uint32_t v = (uint32_t)lane < nbody ? recs[lane] : ZZ_L2_REC_NONE;
-                uint32_t vn = 64u + (uint32_t)lane < nbody ? recs[64 + lane] : ZZ_L2_REC_NONE;
-                uint64_t mb = ballot(v == ZZ_L2_REC_MATCH);
-                uint32_t t = dummy;
-                if (v == ZZ_L2_REC_MATCH) t = tokens[mbcnt(mb)];
-                for (uint32_t r0 = 0; r0 < nbody; r0 += 64) {
-                    const uint32_t rnn = r0 + 128 + (uint32_t)lane;
-                    const uint32_t vnn = rnn < nbody ? recs[rnn] : ZZ_L2_REC_NONE;
-                    mc += (uint32_t)__builtin_popcountll(mb);
-                    const uint64_t mbn = ballot(vn == ZZ_L2_REC_MATCH);
-                    uint32_t tn = dummy;
-                    if (vn == ZZ_L2_REC_MATCH) tn = tokens[mc + mbcnt(mbn)];
-                    uint64_t bits = 0; uint32_t nb = 0;
-                    if (v < ZZ_L2_REC_MATCH) {
-                        const uint32_t cd = codes[v];
-                        bits = cd & 0xFFFF; nb = cd >> 16;
-                    } else if (v == ZZ_L2_REC_MATCH) {
-                        const uint32_t ls = t >> 23, lev = (t >> 18) & 31, bucket = (t >> 13) & 31, dev = t & 0x1FFF;
-                        const uint32_t leb = (ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2;      // luts.cpp:64
-                        const uint32_t deb = bucket < 4 ? 0 : (bucket - 2) >> 1;
-                        const uint32_t lc = codes[257 + ls];
-                        uint32_t ln = lc >> 16;
-                        uint64_t w = (lc & 0xFFFF) | ((uint64_t)lev << ln);         // Merge, :121-124
-                        ln += leb;
-                        const uint32_t dc = dcodes[bucket];
-                        w |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
-                        ln += dc >> 16;
-                        w |= (uint64_t)dev << ln;
-                        ln += deb;
-                        bits = w; nb = ln;
-                    }
-                    ring_append64(ring, bits, nb);
-                    v = vn; vn = vnn; t = tn; mb = mbn;
-                }
-            }
-            {   // codes[256] (:300)
-                const uint32_t cd = codes[256];
-                ring_append_uniform(ring, cd & 0xFFFF, cd >> 16);
+                const uint32_t r1 = ((nbody * 39u) >> 6) & ~63u;     // a little more than half: the helper also has a dry run to do
+                if (lane == 0) { share[0] = 2; share[1] = r1; share[2] = ring.bitpos; }
+                __syncthreads();             // (X)
+                l2_emit_records(ring, recs, tokens, codes, dcodes, 0, r1, 0);
+                ZZ_WAVE_SYNC();
+                if (lane == 0) share[3] = (ring.bitpos & 31) ? ring.ring[(ring.bitpos >> 5) & (ZZ_RING_WORDS - 1)] : 0u;
+                __syncthreads();             // (Y)
+                ZZ_T(5);
+                continue;
             }
         }
         if (!is_final) {
