@@ -185,6 +185,28 @@ def test_host_entry_points(gpu, oracle, corpus):
         zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, True), dest_capacity=100)
 
 
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_host_slab_pipeline(gpu, oracle, corpus, fmt, monkeypatch):
+    """Host buffers longer than one slab take the pipelined path (H2D -> encode -> D2H in slabs of
+    whole packets): same bytes as one call, same 1,000,000-byte callback chunking as the reference."""
+    monkeypatch.setenv("ZZFLATE_SLAB_MIB", "1")
+    d = (corpus["lcet10.txt"] + corpus["ptt5"] + corpus["kennedy.xls"]) * 2 + b"tail"      # ~3.9 MiB: four slabs, ragged end
+    F = [zz.Format.Zlib, zz.Format.Gzip, zz.Format.Deflate][fmt]
+    for lvl in LEVELS:
+        cfg = zz.Config(F, lvl, True)
+        want = oracle.encode_packets(d, fmt, lvl)
+        assert zz.ZzFlateEncode(d, cfg) == want, (fmt, lvl)
+        chunks = []
+        zz.ZzFlateEncodeToCallback(d, cfg, chunks.append)
+        assert b"".join(chunks) == want
+        hl, tl = {0: (2, 4), 1: (10, 8), 2: (0, 0)}[fmt]
+        assert len(chunks[0]) == hl and len(chunks[-1]) == tl
+        body = chunks[1:-1]
+        assert all(len(c) == 1000000 for c in body[:-1]) and 0 < len(body[-1]) <= 1000000   # outputbitstream.h:183
+    with pytest.raises(zz.ZzFlateError):
+        zz.ZzFlateEncode(d, zz.Config(F, 1, True), dest_capacity=len(d) // 4)
+
+
 @pytest.mark.parametrize("lvl", LEVELS)
 def test_shards_concatenate_to_the_whole_stream(gpu, oracle, corpus, lvl):
     """Multi-GPU contract on one GPU: shards cut at packet boundaries + checksum combine == one call."""

@@ -112,14 +112,15 @@ def bound(n, format=Format.Zlib, level=1, packet_size=DEFAULT_PACKET):
 def ZzFlateEncode(source, config, dest_capacity=None):
     """zzflate.h:17 -- returns the encoded bytes. ``dest_capacity`` plays the role of ``*destLen`` on
     entry; a destination that is too small raises (the C entry point sets ``*destLen = ~0``)."""
-    src = bytes(source)
+    import numpy as np
+    src = source if isinstance(source, bytes) else bytes(source)
     cap = bound(len(src), config.format, config.level, lib.zz_get_packet_size()) if dest_capacity is None else dest_capacity
-    dest = ctypes.create_string_buffer(max(cap, 1))
+    dest = np.empty(max(cap, 1), dtype=np.uint8)           # not zero-filled: the library writes it
     n = ctypes.c_uint64(cap)
     c = _cfg(config)
-    rc = lib.zz_encode(dest, ctypes.byref(n), src, len(src), ctypes.byref(c))
+    rc = lib.zz_encode(dest.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), src, len(src), ctypes.byref(c))
     _check(rc)
-    return dest.raw[: n.value]
+    return dest[: n.value].tobytes()
 
 
 def ZzFlateEncodeToCallback(source, config, callback):

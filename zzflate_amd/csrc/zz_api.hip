@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +53,12 @@ struct zz_ctx {
     // staging for the host-buffer entry points
     uint8_t* stage_in = nullptr;  uint64_t stage_in_cap = 0;
     uint8_t* stage_out = nullptr; uint64_t stage_out_cap = 0;
+    // slab pipeline of the host-buffer entry points: pinned slabs in and out, device output slabs, three streams
+    uint8_t* pin_in[2] = { nullptr, nullptr };  uint64_t pin_in_cap = 0;
+    uint8_t* pin_out[2] = { nullptr, nullptr }; uint64_t pin_out_cap = 0;
+    uint8_t* slab_out[2] = { nullptr, nullptr }; uint64_t slab_out_cap = 0;
+    hipStream_t s_in = nullptr, s_enc = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_out[2] = { nullptr, nullptr };
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_time = false;
@@ -116,6 +123,14 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     (void)hipFree(c->l2_scratch);
     (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
     (void)hipFree(c->stage_in); (void)hipFree(c->stage_out);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipHostFree(c->pin_in[i]); (void)hipHostFree(c->pin_out[i]); (void)hipFree(c->slab_out[i]);
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_enc) (void)hipStreamDestroy(c->s_enc);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     (void)hipHostFree(c->h_res);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -491,22 +506,187 @@ static int ensure_stage(zz_ctx* c, uint64_t in_bytes, uint64_t out_bytes)
     return ZZ_OK;
 }
 
-// shared by zz_encode / zz_encode_callback: compress host src into the context's device staging buffer
-static int encode_host_to_stage(zz_ctx* c, const uint8_t* src, uint64_t n, const zz_config* cfg, uint64_t* total)
+// ---- host-buffer entry points ------------------------------------------------------------------------------------
+// Where the compressed bytes go: straight into the caller's destination (ZzFlateEncode, zzflate.cpp:225-242) or
+// through the callback in library-owned chunks of at most 1,000,000 bytes (ZzFlateEncodeToCallback, zzflate.cpp:
+// 197-222, outputbitstream.h:183): header and trailer are calls of their own, as in the reference.
+struct host_sink {
+    // destination form
+    uint8_t* dest = nullptr; uint64_t cap = 0, pos = 0; bool overflow = false;
+    // callback form
+    zz_callback cb = nullptr; void* user = nullptr; std::vector<uint8_t> chunk;
+    void raw(const uint8_t* p, uint64_t n)            // header / trailer
+    {
+        if (cb) { flush(); cb(user, p, n); return; }
+        put(p, n);
+    }
+    void put(const uint8_t* p, uint64_t n)            // stream bytes
+    {
+        if (!cb) {
+            if (overflow || n > cap - pos) { overflow = true; return; }
+            memcpy_mt(dest + pos, p, n);
+            pos += n;
+            return;
+        }
+        while (n) {
+            const uint64_t room = 1000000 - chunk.size();
+            const uint64_t k = n < room ? n : room;
+            chunk.insert(chunk.end(), p, p + k);
+            p += k; n -= k;
+            if (chunk.size() == 1000000) flush();
+        }
+    }
+    void flush() { if (cb && !chunk.empty()) { cb(user, chunk.data(), chunk.size()); chunk.clear(); } }
+    static void memcpy_mt(uint8_t* d, const uint8_t* s, uint64_t n)
+    {
+        // pageable <-> pinned copies of whole slabs: a few threads reach the memory bandwidth one thread cannot
+        const uint64_t piece = 8ull << 20;
+        if (n < 2 * piece) { memcpy(d, s, n); return; }
+        const unsigned nt = (unsigned)((n + piece - 1) / piece < 8 ? (n + piece - 1) / piece : 8);
+        const uint64_t per = ((n + nt - 1) / nt + 4095) & ~4095ull;
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) {
+            const uint64_t o = (uint64_t)t * per;
+            if (o >= n) break;
+            th.emplace_back([=] { memcpy(d + o, s + o, n - o < per ? n - o : per); });
+        }
+        memcpy(d, s, per < n ? per : n);
+        for (auto& x : th) x.join();
+    }
+};
+
+static uint64_t slab_bytes(uint32_t P)
 {
-    const int level = cfg->level;
-    if (level < 0 || level > 3) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
-    const uint32_t P = zz_get_packet_size();
-    int format = cfg->format;
-    if (format < 0 || format > 2) format = ZZ_DEFLATE;
-    const bool sequential = !cfg->threaded && n > P;   // more than one packet: the reference's whole-buffer stream
+    uint64_t mib = 64;
+    if (const char* e = getenv("ZZFLATE_SLAB_MIB")) { const long v = atol(e); if (v >= 1 && v <= 4096) mib = (uint64_t)v; }
+    const uint64_t s = mib << 20;
+    return s < P ? P : s / P * P;          // slabs are cut at packet boundaries
+}
+
+static int ensure_pipe(zz_ctx* c, uint64_t slab, uint64_t slab_bound)
+{
+    if (!c->s_in) {
+        HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->s_enc, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    if (slab > c->pin_in_cap) {
+        for (int i = 0; i < 2; ++i) { (void)hipHostFree(c->pin_in[i]); c->pin_in[i] = nullptr; }
+        c->pin_in_cap = 0;
+        for (int i = 0; i < 2; ++i) HIPCHK(hipHostMalloc((void**)&c->pin_in[i], slab, hipHostMallocDefault));
+        c->pin_in_cap = slab;
+    }
+    if (slab_bound > c->pin_out_cap) {
+        for (int i = 0; i < 2; ++i) { (void)hipHostFree(c->pin_out[i]); c->pin_out[i] = nullptr; (void)hipFree(c->slab_out[i]); c->slab_out[i] = nullptr; }
+        c->pin_out_cap = c->slab_out_cap = 0;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipHostMalloc((void**)&c->pin_out[i], slab_bound, hipHostMallocDefault));
+            HIPCHK(hipMalloc(&c->slab_out[i], slab_bound + 64));
+        }
+        c->pin_out_cap = c->slab_out_cap = slab_bound;
+    }
+    return ZZ_OK;
+}
+
+// Packet mode on a host buffer, SURVEY.md 8(f).1: the input crosses PCIe in slabs of whole packets while earlier
+// slabs are encoded (as shards of one stream: no container, checksum partials combined here) and their output
+// travels back. Three streams, two pinned buffers per direction; the device keeps the whole input (level >= 2
+// looks up to 258 bytes behind a slab's first byte).
+static int encode_host_pipelined(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, uint32_t P, host_sink& sink)
+{
+    const uint64_t slab = slab_bytes(P);
+    const uint64_t nslab = (n + slab - 1) / slab;
+    const uint64_t sb = zz_bound(slab, ZZ_DEFLATE, level, P);
+    int rc = ensure_stage(c, n, 0);
+    if (rc) return rc;
+    rc = ensure_pipe(c, slab, sb);
+    if (rc) return rc;
+    const int ck = format == ZZ_ZLIB ? ZZ_ZLIB : format == ZZ_GZIP ? ZZ_GZIP : ZZ_DEFLATE;
+    uint8_t hdr[10], trl[8];
+    sink.raw(hdr, (uint64_t)zz_header(format, hdr));
+    uint32_t acc = format == ZZ_ZLIB ? 1u : 0u;          // running checksum of everything in front of the slab
+    std::vector<uint64_t> out_len(nslab, 0);
+    auto stage_in = [&](uint64_t i) -> int {
+        const uint64_t off = i * slab, len = n - off < slab ? n - off : slab;
+        const int b = (int)(i & 1);
+        if (i >= 2) HIPCHK(hipEventSynchronize(c->ev_in[b]));                 // the slab that used this buffer has left it
+        host_sink::memcpy_mt(c->pin_in[b], src + off, len);
+        HIPCHK(hipMemcpyAsync(c->stage_in + off, c->pin_in[b], len, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(hipEventRecord(c->ev_in[b], c->s_in));
+        return ZZ_OK;
+    };
+    auto deliver = [&](uint64_t i) -> int {
+        const int b = (int)(i & 1);
+        HIPCHK(hipEventSynchronize(c->ev_out[b]));
+        sink.put(c->pin_out[b], out_len[i]);
+        return ZZ_OK;
+    };
+    rc = stage_in(0);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < nslab; ++i) {
+        const uint64_t off = i * slab, len = n - off < slab ? n - off : slab;
+        const int b = (int)(i & 1);
+        if (i + 1 < nslab) { rc = stage_in(i + 1); if (rc) return rc; }       // next slab's copy runs under this slab's encode
+        HIPCHK(hipStreamWaitEvent(c->s_enc, c->ev_in[b], 0));
+        if (i >= 2) HIPCHK(hipStreamWaitEvent(c->s_enc, c->ev_out[b], 0));    // the output slab is free again
+        uint64_t w = 0; uint32_t part = 0;
+        rc = zz_encode_shard_device(c, c->stage_in + off, len, off, i + 1 == nslab, c->slab_out[b], c->slab_out_cap, &w, &part,
+                                    ck, level, P, (void*)c->s_enc);     // returns when the slab is encoded
+        if (rc) return rc;
+        out_len[i] = w;
+        acc = format == ZZ_ZLIB ? adler_combine(acc, part, len) : format == ZZ_GZIP ? crc32_combine(acc, part, len) : 0u;
+        HIPCHK(hipMemcpyAsync(c->pin_out[b], c->slab_out[b], w, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipEventRecord(c->ev_out[b], c->s_out));
+        if (i >= 1) { rc = deliver(i - 1); if (rc) return rc; }
+    }
+    rc = deliver(nslab - 1);
+    if (rc) return rc;
+    sink.raw(trl, (uint64_t)zz_trailer(format, acc, n, trl));
+    sink.flush();
+    return ZZ_OK;
+}
+
+// everything else (one slab or less, or the sequential whole-buffer stream): one copy in, one call, one copy out
+static int encode_host_simple(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, uint32_t P, bool sequential,
+                              host_sink& sink)
+{
     const uint64_t bound = zz_bound(n, format, level, P);
-    HIPCHK(hipSetDevice(c->device));
     int rc = ensure_stage(c, n, bound);
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpy(c->stage_in, src, n, hipMemcpyHostToDevice));
-    if (sequential) return zz_encode_stream_device(c, c->stage_in, n, c->stage_out, bound, total, format, level, nullptr);
-    return zz_encode_device(c, c->stage_in, n, c->stage_out, bound, total, format, level, P, nullptr);
+    uint64_t total = 0;
+    rc = sequential ? zz_encode_stream_device(c, c->stage_in, n, c->stage_out, bound, &total, format, level, nullptr)
+                    : zz_encode_device(c, c->stage_in, n, c->stage_out, bound, &total, format, level, P, nullptr);
+    if (rc) return rc;
+    std::vector<uint8_t> host(total);
+    if (total) HIPCHK(hipMemcpy(host.data(), c->stage_out, total, hipMemcpyDeviceToHost));
+    const uint64_t hl = header_len(format), tl = trailer_len(format);
+    sink.raw(host.data(), hl);
+    sink.put(host.data() + hl, total - hl - tl);
+    sink.raw(host.data() + total - tl, tl);
+    sink.flush();
+    return ZZ_OK;
+}
+
+static int encode_host(const uint8_t* src, uint64_t n, const zz_config* cfg, host_sink& sink)
+{
+    const int level = cfg->level;
+    if (level < 0 || level > 3) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    zz_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    const uint32_t P = zz_get_packet_size();
+    int format = cfg->format;
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    HIPCHK(hipSetDevice(c->device));
+    const bool sequential = !cfg->threaded && n > P;   // more than one packet: the reference's whole-buffer stream
+    if (!sequential && n > slab_bytes(P)) return encode_host_pipelined(c, src, n, format, level, P, sink);
+    return encode_host_simple(c, src, n, format, level, P, sequential, sink);
 }
 
 extern "C" int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, uint64_t n, const zz_config* cfg)
@@ -515,45 +695,23 @@ extern "C" int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, 
     const uint64_t cap = *dest_len;
     *dest_len = ~0ull;
     if (!cfg || !dest) { set_err("null argument"); return ZZ_E_ARG; }
-    std::lock_guard<std::mutex> lk(g_mu);
-    zz_ctx* c;
-    int rc = default_ctx(&c);
-    if (rc) return rc;
     if (cap < (uint64_t)header_len(cfg->format)) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
-    uint64_t total = 0;
-    rc = encode_host_to_stage(c, src, n, cfg, &total);
+    host_sink sink;
+    sink.dest = dest; sink.cap = cap;
+    const int rc = encode_host(src, n, cfg, sink);
     if (rc) return rc;
-    if (total > cap) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
-    HIPCHK(hipMemcpy(dest, c->stage_out, total, hipMemcpyDeviceToHost));
-    *dest_len = total;
+    if (sink.overflow) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    *dest_len = sink.pos;
     return ZZ_OK;
 }
 
 extern "C" int zz_encode_callback(const uint8_t* src, uint64_t n, const zz_config* cfg, zz_callback cb, void* user)
 {
     if (!cfg || !cb) { set_err("null argument"); return ZZ_E_ARG; }
-    std::lock_guard<std::mutex> lk(g_mu);
-    zz_ctx* c;
-    int rc = default_ctx(&c);
-    if (rc) return rc;
-    uint64_t total = 0;
-    rc = encode_host_to_stage(c, src, n, cfg, &total);
-    if (rc) return rc;
-    std::vector<uint8_t> host(total);
-    if (total) HIPCHK(hipMemcpy(host.data(), c->stage_out, total, hipMemcpyDeviceToHost));
-    int format = cfg->format;
-    if (format < 0 || format > 2) format = ZZ_DEFLATE;
-    const uint64_t hl = header_len(format), tl = trailer_len(format);
-    // zzflate.cpp:204-221: header, then the stream in library-owned chunks, then the trailer
-    cb(user, host.data(), hl);
-    uint64_t pos = hl, end = total - tl;
-    while (pos < end) {
-        uint64_t k = end - pos < 1000000 ? end - pos : 1000000;   // outputbitstream.h:183
-        cb(user, host.data() + pos, k);
-        pos += k;
-    }
-    cb(user, host.data() + end, tl);
-    return ZZ_OK;
+    host_sink sink;
+    sink.cb = cb; sink.user = user;
+    sink.chunk.reserve(1000000);
+    return encode_host(src, n, cfg, sink);
 }
 
 // ---- synthetic inputs -----------------------------------------------------------------------------------------
