@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--gen", default="text", choices=list(GEN))
     ap.add_argument("--format", default="zlib", choices=["zlib", "gzip", "deflate"])
     ap.add_argument("--packet", type=int, default=32768)
-    ap.add_argument("--chunks", type=int, default=4, help="N > 1: pieces per shard; piece c travels to rank 0 "
-                    "while piece c+1 is encoded (1 = one gather after the whole shard)")
+    ap.add_argument("--chunks", type=int, default=1, help="N > 1: 1 = one launch and one gather per step, the gather left in "
+                    "flight under the next step's encoding (double-buffered); C > 1 = C pieces per shard, piece c "
+                    "travels to rank 0 while piece c+1 is encoded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
@@ -148,6 +149,10 @@ def main():
     shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
     xdev = "cuda" if backend == "nccl" else "cpu"     # where the exchange buffers live
     gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (world > 1 and rank == 0) else None
+    # step-overlapped mode: a second pair of buffers, so that step i's gather can still be in flight during step i+1
+    shard_b = [shard, torch.empty(cap, dtype=torch.uint8, device="cuda") if world > 1 else None]
+    gathered_b = [gathered, torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (world > 1 and rank == 0) else None]
+    pending = [None, None]
     C = max(1, args.chunks) if world > 1 else 1
     assert n % (C * P) == 0, "--mib must split into --chunks packet-aligned pieces"
     pipe = None
@@ -166,13 +171,20 @@ def main():
             state["comp_bytes"] = w
         elif pipe is None:
             from zzflate_amd import sharded
-            w, cks = ctx.encode_shard(src, n, shard, cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
+            b = state.get("step", 0) & 1
+            state["step"] = state.get("step", 0) + 1
+            if pending[b] is not None:                      # the gather that used this pair of buffers two steps ago
+                tot = pending[b].wait()
+                pending[b] = None
+                if rank == 0:
+                    state["out_bytes"] = tot
+            w, cks = ctx.encode_shard(src, n, shard_b[b], cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
                                       level=args.level, packet_size=P)
-            # sizes/checksums all-gather + ONE grouped send/recv gather of the compressed shards to rank 0
-            xshard = shard if backend == "nccl" else shard[:w].cpu()
-            tot = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered)
-            if rank == 0:
-                state["out_bytes"] = tot
+            # sizes/checksums all-gather + ONE grouped send/recv gather of the compressed shards to rank 0, left in
+            # flight: the next step encodes into the other buffers meanwhile
+            xshard = shard_b[b] if backend == "nccl" else shard_b[b][:w].cpu()
+            pending[b] = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b], wait=False)
+            state["last_buf"] = b
             state["comp_bytes"] = w
         else:
             # the shard in C pieces: piece c is on its way to rank 0 (async grouped send/recv) while c+1 is encoded
@@ -196,6 +208,12 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
 
     def barrier():
+        for b in (0, 1):                                    # every gather has landed before the clock is read
+            if pending[b] is not None:
+                tot = pending[b].wait()
+                pending[b] = None
+                if rank == 0:
+                    state["out_bytes"] = tot
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -218,7 +236,7 @@ def main():
     check = {}
     if rank == 0:
         import zlib
-        out_t = shard if world == 1 else gathered
+        out_t = shard if world == 1 else gathered_b[state.get("last_buf", 0)]
         k = min(state["out_bytes"], 96 << 20)
         head = out_t[:k].cpu().numpy().tobytes()
         o = zlib.decompressobj({0: 15, 1: 31, 2: -15}[fmt])
@@ -283,7 +301,7 @@ def main():
             "config": {
                 "workload": f"{args.mib} MiB synthetic {args.gen} per GPU (zz_generate_device kind={args.gen}, seed "
                             f"{SEEDS[args.gen]:#x}), level {args.level}, {args.format} container, {P}-byte packets, "
-                            f"input and output resident in HBM" + (f", shards gathered to rank 0 over RCCL in {C} overlapped piece(s)" if world > 1 else ""),
+                            f"input and output resident in HBM" + ((", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if world > 1 else ""),
                 "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format,
             },
             "roofline": {

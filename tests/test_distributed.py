@@ -47,7 +47,14 @@ def _worker(rank, world, port, fname, fmt, lvl, P, result_path, chunks=1):
     outbuf = torch.zeros(2 * len(data) + 4096, dtype=torch.uint8) if rank == 0 else None
     if chunks <= 1:
         shard = torch.frombuffer(bytearray(out) if out else bytearray(1), dtype=torch.uint8)
-        total = sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf)
+        # two streams in flight at once (what bench.py does across steps), then the plain blocking form
+        outbuf2 = torch.zeros_like(outbuf) if rank == 0 else None
+        h1 = sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf2, wait=False)
+        h2 = sharded.gather_stream(dist, fmt, shard.clone(), len(out), cks, n, outbuf, wait=False)
+        t1, total = h1.wait(), h2.wait()
+        if rank == 0:
+            assert t1 == total and bytes(outbuf2[:t1].numpy()) == bytes(outbuf[:total].numpy())
+        assert sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf) == total
     else:
         # pipelined variant: the shard leaves in `chunks` packet-aligned pieces
         pg = sharded.PipelinedGather(dist, fmt, 2 * len(data) + 4096, torch.device("cpu"))

@@ -41,10 +41,25 @@ def combine_checksums(fmt, parts):
     return 0
 
 
-def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None):
+class _Pending:
+    """A gather whose transfers may still be in flight: `wait()` before touching `shard` or `out` again."""
+
+    def __init__(self, reqs, total, keep):
+        self.reqs, self.total, self.keep = reqs, total, keep
+
+    def wait(self):
+        for req in self.reqs:
+            req.wait()
+        self.reqs, self.keep = [], None
+        return self.total
+
+
+def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None, wait=True):
     """Collective. `shard[:shard_bytes]` is this rank's compressed shard (uint8 tensor), `cks` its checksum
     partial, `n_in` its input byte count. On rank 0 returns the total stream length written into `out`
-    (header + shards + trailer); elsewhere returns None."""
+    (header + shards + trailer); elsewhere returns None. With wait=False the grouped send/recv is left in flight and
+    a handle comes back instead (`.wait()` -> the same result): the caller encodes its next stream into other
+    buffers meanwhile, so the transfer over xGMI hides behind compute."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = shard.device
     meta = torch.tensor([shard_bytes, cks, n_in], dtype=torch.int64, device=dev)
@@ -66,17 +81,17 @@ def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None
         out[offs[0]:offs[0] + sizes[0]].copy_(shard[:sizes[0]])
     elif sizes[rank]:
         ops.append(dist.P2POp(dist.isend, shard[:sizes[rank]], 0, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    if rank != 0:
-        return None
-    tail = trailer(fmt, combine_checksums(fmt, list(zip(ckss, lens))), sum(lens))
-    if head:
-        out[:len(head)].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
-    if tail:
-        out[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
-    return off + len(tail)
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    total = None
+    if rank == 0:
+        tail = trailer(fmt, combine_checksums(fmt, list(zip(ckss, lens))), sum(lens))
+        if head:
+            out[:len(head)].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
+        if tail:
+            out[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
+        total = off + len(tail)
+    pending = _Pending(reqs, total, (shard, out))
+    return pending.wait() if wait else pending
 
 
 class PipelinedGather:
