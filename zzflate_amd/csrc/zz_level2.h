@@ -766,16 +766,23 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
 // records through nrec_out.
 __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
                                                    uint32_t* tokens, uint16_t* recs, const uint8_t* src, uint32_t n,
-                                                   uint32_t& nrec_out)
+                                                   uint32_t& nrec_out, uint32_t& adA, uint64_t& adC)
 {
     const int lane = lane_id();
     const uint32_t trips = l2_probe_blocks(n);
     uint32_t nrec = 0, Fnext = 0, ntok = 0;
+    // Adler-32 on the way: every byte below n passes through this wave once (as the byte of a finished block), so the
+    // per-lane sums of d and position * d (wave_adler's A and C) cost two instructions here instead of a pass of their own
+    adA = 0; adC = 0;
     for (uint32_t i = 0; i < trips; ++i) {
         const uint32_t base = i << 6;
         // the block that becomes final in this trip: its bytes are fetched before the wait
         uint32_t fbyte = 0;
-        if (i >= ZZ_L2_LAG) fbyte = src[base + lane - 64 * ZZ_L2_LAG];
+        if (i >= ZZ_L2_LAG) {
+            const uint32_t p = base + lane - 64 * ZZ_L2_LAG;        // < n: the probe front is at least 258 bytes from the end
+            fbyte = src[p];
+            adA += fbyte; adC += (uint64_t)p * fbyte;
+        }
         l2_block_barrier();
         const uint32_t* slot = hb + (i & 1) * ZZ_L2_HB_WORDS;
         const uint32_t pk = slot[lane];
@@ -812,7 +819,9 @@ __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t*
     ZZ_WAVE_SYNC();
     for (const uint32_t nblk = (n + 63) >> 6; Fnext < nblk; ++Fnext) {       // the tail nobody probes (:222) + the lag
         const uint32_t p = (Fnext << 6) + (uint32_t)lane;
-        nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, p < n ? src[p] : 0u);
+        const uint32_t d = p < n ? src[p] : 0u;
+        adA += d; adC += (uint64_t)p * d;
+        nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, d);
     }
     nrec_out = nrec;
     return ntok;
@@ -902,9 +911,8 @@ struct zz_l2_params {
 #define ZZ_WAVE_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 
 // Two wavefronts per packet. During the token pass wavefront 0 parses (hash table, candidates, the serial walk) and
-// wavefront 1 keeps the books (matches to scratch, bitmap window, symbol counts, finished blocks to records), one
-// s_barrier per 64-position block. Afterwards wavefront 0 builds the codes and emits while wavefront 1 computes the
-// packet's Adler-32.
+// wavefront 1 keeps the books (matches to scratch, bitmap window, symbol counts, finished blocks to records, the
+// Adler-32 sums), one s_barrier per 64-position block. Afterwards wavefront 0 builds the codes and both emit.
 __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
@@ -973,17 +981,27 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
                 if (k + 2 >= P.npk) l2_token_pass<true>(T, hb, src, end, n, before, P.prof);
                 else l2_token_pass<false>(T, hb, src, end, n, before, P.prof);
             } else {
-                uint32_t nb = 0;
-                const uint32_t nt = l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb);
+                uint32_t nb = 0, adA = 0;
+                uint64_t adC = 0;
+                const uint32_t nt = l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC);
                 if (lane == 0) { covw[0] = ((uint64_t)nt << 32) | nb; }       // the window is dead now
+                if (P.cks_kind == ZZ_CKS_ADLER) {
+                    if (lane == 0 && len > n) { const uint32_t d = src[n]; adA += d; adC += (uint64_t)n * d; }   // the byte of the alignment block
+                    const uint64_t At = wave_sum64(adA), Ct = wave_sum64(adC);
+                    if (lane == 0) {
+                        zz_cks c;
+                        c.a = (uint32_t)(At % ZZ_ADLER_MOD);
+                        c.b = (uint32_t)(((uint64_t)len * At - Ct) % ZZ_ADLER_MOD);
+                        P.cks[k] = c;
+                    }
+                }
             }
             __syncthreads();   // counts, window and the helper's global stores are complete
         }
         uint32_t* share = misc + 4;      // [0] 1 stored / 2 dynamic, [1] first record of the helper's part, [2] bits in front of
                                          // the records, [3] wavefront 0's last (partial) word, [4] the helper's first word
         if (wave != 0) {
-            // the checksum while wavefront 0 builds the codes ...
-            if (P.cks_kind == ZZ_CKS_ADLER) {
+            if (n == 0 && P.cks_kind == ZZ_CKS_ADLER) {     // (n > 0: summed during the token pass)
                 zz_cks c = wave_adler(src, len);
                 if (lane == 0) P.cks[k] = c;
             }
