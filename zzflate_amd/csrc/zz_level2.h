@@ -509,8 +509,12 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
 // Hand-over from the parsing wavefront to the helper wavefront, one slot per 64-position block, two slots:
 // word l = lane l's match (ZZ_L2_HB_*), words 64,65 = mask of lanes that found one. The helper picks a slot up behind
 // barrier i; the parser overwrites it after barrier i + 1.
-#define ZZ_L2_HB_WORDS 66u
+// (A lane the C++ path finished carries start, length, distance: ZZ_L2_HB_PACK; a lane the scalar loop only marked
+// carries its forward length, its usable backward length and the distance -- the helper works out where the match
+// starts: words 66,67 = mask of the finished lanes, word 68 = backRefEnd when the block was entered.)
+#define ZZ_L2_HB_WORDS 70u
 #define ZZ_L2_HB_PACK(ms, mlen, dist, base) (((ms) + 258u - (base)) | (((mlen) - 3u) << 9) | ((dist) << 17))
+#define ZZ_L2_HB_PACK_FAST(fwd, broom, dist) ((fwd) | ((broom) << 5) | ((dist) << 17))
 __device__ __forceinline__ void l2_block_barrier()
 {
     // this wave's LDS traffic must have landed; its global loads (prefetches) stay in flight
@@ -639,7 +643,6 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 const uint64_t m = endl >= 64 ? 0 : (Amask & (~0ull << endl));
                 winfo |= (m ? (uint32_t)__builtin_ctzll(m) : 64u) << 16;
             }
-            uint32_t endp = q + fwd8;       // backRefEnd after a match at this lane (slow tokens overwrite theirs)
             uint32_t tk = 0;                // start | len << 16, slow tokens only; the others are filled in below
             uint64_t evmask = 0, slowmask = 0;
             const uint32_t Bentry = B;
@@ -725,29 +728,23 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                           // :412-415
                 const uint32_t ms = qe - bw;                                                        // :416
                 B = ms + mlen;                                                                      // :422
-                if (lane == e) { tk = ms | (mlen << 16); endp = B; }                                // :420
+                if (lane == e) tk = ms | (mlen << 16);                                              // :420
                 evmask |= 1ull << e;
                 slowmask |= 1ull << e;
                 nextProbe = B + 1;                                                                  // :424
                 if (nextProbe >= base + 64) break;
             }
-            // starts and lengths of the matches the scalar loop marked: the backward part is limited by the literals
-            // pending since the previous match of this block (or since the block was entered)
-            if (evmask & ~slowmask) {
-                const uint64_t prev = evmask & ((1ull << lane) - 1);
-                const int pl = prev ? 63 - __builtin_clzll(prev) : lane;
-                const uint32_t pend_end = (uint32_t)__shfl((int)endp, pl);
-                if (((evmask & ~slowmask) >> lane) & 1) {
-                    const uint32_t pe = q - (prev ? pend_end : Bentry);
-                    const uint32_t bq = broom < pe ? broom : pe;
-                    tk = (q - bq) | ((fwd8 + bq) << 16);
-                }
-            }
             ZZ_T(9);
-            // ---- hand this block's matches to the helper wavefront ------------------------------------------------
+            // ---- hand this block's matches to the helper wavefront (which also fills in the starts and lengths of the
+            // matches the scalar loop only marked) ---------------------------------------------------------------------
             uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
-            if ((evmask >> lane) & 1) slot[lane] = ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, q - c, base);
-            if (lane == 0) { slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32); }
+            if ((evmask >> lane) & 1)
+                slot[lane] = ((slowmask >> lane) & 1) ? ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, q - c, base) : ZZ_L2_HB_PACK_FAST(fwd8, broom, q - c);
+            if (lane == 0) {
+                slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32);
+                slot[66] = (uint32_t)slowmask; slot[67] = (uint32_t)(slowmask >> 32);
+                slot[68] = Bentry;
+            }
         } else if (lane == 0) {
             uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
             slot[64] = 0; slot[65] = 0;
@@ -788,8 +785,26 @@ __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t*
         const uint32_t pk = slot[lane];
         const uint64_t evmask = ((uint64_t)uniform(slot[65]) << 32) | uniform(slot[64]);
         if (evmask) {
+            const uint64_t slowmask = ((uint64_t)uniform(slot[67]) << 32) | uniform(slot[66]);
+            const uint32_t Bentry = uniform(slot[68]);
+            const uint32_t q = base + (uint32_t)lane;
+            const bool slow = (slowmask >> lane) & 1;
+            uint32_t ms = base + (pk & 0x1FF) - 258u, mlen = ((pk >> 9) & 0xFF) + 3u;       // as the C++ path left them
+            // matches the scalar loop only marked: backRefEnd after a match is probe + forward length (:416,422); the
+            // backward part is limited by the literals pending since the previous match of this block (or since the
+            // block was entered, :404-407)
+            const uint32_t fwd8 = pk & 31, broom = (pk >> 5) & 15;
+            const uint32_t endp = slow ? ms + mlen : q + fwd8;
+            const uint64_t prev = evmask & ((1ull << lane) - 1);
+            const int pl = prev ? 63 - __builtin_clzll(prev) : lane;
+            const uint32_t pend_end = (uint32_t)__shfl((int)endp, pl);            // every lane takes part
+            if (!slow) {
+                const uint32_t pe = q - (prev ? pend_end : Bentry);
+                const uint32_t bq = broom < pe ? broom : pe;
+                ms = q - bq; mlen = fwd8 + bq;
+            }
             if ((evmask >> lane) & 1) {
-                const uint32_t ms = base + (pk & 0x1FF) - 258u, mlen = ((pk >> 9) & 0xFF) + 3u, dist = pk >> 17;
+                const uint32_t dist = pk >> 17;
                 uint32_t sym, leb, lev, bucket, deb, dev;            // GetFrequencies, :455-463
                 length_symbol(mlen, sym, leb, lev);
                 dist_symbol(dist, bucket, deb, dev);
@@ -905,7 +920,7 @@ struct zz_l2_params {
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
 };
 
-#define ZZ_L2_LDS_BYTES (16384 + 528 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
+#define ZZ_L2_LDS_BYTES (16384 + 560 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
 #define ZZ_L2_THREADS (2 * ZZ_WAVE)
 // one wave's own memory traffic has landed (the code after the token pass runs on wavefront 0 alone: no s_barrier there)
 #define ZZ_WAVE_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
@@ -916,7 +931,7 @@ struct zz_l2_params {
 __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
-    // ---- LDS carve-up: 17,808 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
+    // ---- LDS carve-up: 17,840 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
     // The hash table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the
     // code tables all live inside it; the bit ring (used after the token pass) shares its space with the
     // hand-over slots (used during it); the bitmap window and the packed counters have their own.
@@ -928,11 +943,11 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
     uint32_t* dcodes = (uint32_t*)(lds + 8192 + 1280 + 1152);     // 128: 30 distance codes
     uint32_t* metaF = (uint32_t*)(lds + 8192 + 1280 + 1152 + 128);            // 80: 19 meta frequencies
     uint32_t* misc = (uint32_t*)(lds + 11264);                    // 256: lane-0 results [0..3], code-generation work area [16..48)
-    uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512 (+16 pad)
-    uint32_t* hb = (uint32_t*)(lds + 16384);                      // 528: two hand-over slots, same bytes as the ring
-    uint64_t* covw = (uint64_t*)(lds + 16384 + 528);              // 128: covered bits of the 16 blocks around the probe front
+    uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512 (+48 pad)
+    uint32_t* hb = (uint32_t*)(lds + 16384);                      // 560: two hand-over slots, same bytes as the ring
+    uint64_t* covw = (uint64_t*)(lds + 16384 + 560);              // 128: covered bits of the 16 blocks around the probe front
     uint64_t* mstw = covw + ZZ_L2_WIN;                            // 128: match-start bits
-    uint32_t* histP = (uint32_t*)(lds + 16384 + 528 + 2 * ZZ_L2_WIN * 8);     // 640: packed 16-bit counters
+    uint32_t* histP = (uint32_t*)(lds + 16384 + 560 + 2 * ZZ_L2_WIN * 8);     // 640: packed 16-bit counters
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
