@@ -232,8 +232,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # ---- validation of what was just measured (untimed): inflate a prefix, check sizes -------------------
+    # ---- validation of what was just measured (untimed) ----------------------------------------------------------
+    # every packet this rank produced in the last step is inflated on the device and compared with its input
+    # (zz_verify_last_device: a plain RFC 1951 decoder, one lane per packet); rank 0 also inflates a prefix with zlib
     check = {}
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    bad, first_bad = ctx.verify_last()
+    tv = time.perf_counter() - tv
+    if world > 1:
+        tb = torch.tensor([bad], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tb)
+        bad = int(tb.item())
+    check["device_inflate"] = {"packets": ((n + P - 1) // P) * world, "bad": bad, "seconds_rank0": round(tv, 3)}
     if rank == 0:
         import zlib
         out_t = shard if world == 1 else gathered_b[state.get("last_buf", 0)]

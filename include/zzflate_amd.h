@@ -103,6 +103,13 @@ int zz_encode_shard_device(zz_ctx* ctx, const void* d_src, uint64_t n, uint64_t 
                            void* d_dst, uint64_t cap, uint64_t* out_len, uint32_t* cks, int checksum,
                            int level, uint32_t packet_size, void* hip_stream);
 
+/* Self-verification: inflates, on the device, every packet of the stream the LAST zz_encode_device /
+ * zz_encode_shard_device call on this context produced, and compares with that call's input (both buffers must still
+ * be in place). *bad_packets = packets that do not decode to their input, *first_bad_packet = the lowest such packet
+ * (~0 if none). A checker for tests, benchmarks and deployments that want an end-to-end guarantee; the reference has
+ * no decoder (decoder.h is an empty stub). */
+int zz_verify_last_device(zz_ctx* ctx, uint64_t* bad_packets, uint64_t* first_bad_packet, void* hip_stream);
+
 /* container pieces for assembling shards on the host */
 int zz_header(int format, uint8_t out[10]);                                   /* returns 0/2/10 */
 int zz_trailer(int format, uint32_t cks_total, uint64_t n, uint8_t out[8]);   /* returns 0/4/8  */

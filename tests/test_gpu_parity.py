@@ -185,6 +185,37 @@ def test_host_entry_points(gpu, oracle, corpus):
         zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, True), dest_capacity=100)
 
 
+@pytest.mark.parametrize("lvl", LEVELS)
+def test_device_inflate_self_check(gpu, corpus, lvl):
+    """zz_verify_last_device: every packet of a stream inflates, on the device, to its input; a
+    damaged packet is found. Independent of the oracle: a plain RFC 1951 decoder, one lane per packet."""
+    import torch
+    for name, P in (("alice29.txt", 32768), ("kennedy.xls", 4096), ("ptt5", 32768), ("fields.c", 1000)):
+        d = corpus[name]
+        n = len(d)
+        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        cap = zz.bound(n, 0, lvl, P)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = gpu.ctx.encode(src, n, dst, cap, 0, lvl, P)
+        assert gpu.ctx.verify_last() == (0, None), (name, lvl)
+        # damage one byte in the middle of the stream: some packet must fail, and it must be near that byte
+        pos = 2 + (w - 6) // 2
+        dst[pos] ^= 0x5A
+        bad, first = gpu.ctx.verify_last()
+        assert bad >= 1 and first is not None, (name, lvl)
+        dst[pos] ^= 0x5A
+        assert gpu.ctx.verify_last() == (0, None)
+    # the data generators at a size host zlib would need seconds for
+    n = 64 << 20
+    for kind in (zz.GEN_TEXT, zz.GEN_MIX, zz.GEN_RANDOM):
+        src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        gpu.ctx.generate(kind, 0x5EED0002, 0, src, n)
+        cap = zz.bound(n, 1, lvl, 32768)
+        dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        gpu.ctx.encode(src, n, dst, cap, 1, lvl)
+        assert gpu.ctx.verify_last() == (0, None), (kind, lvl)
+
+
 @pytest.mark.parametrize("fmt", [0, 1, 2])
 def test_host_slab_pipeline(gpu, oracle, corpus, fmt, monkeypatch):
     """Host buffers longer than one slab take the pipelined path (H2D -> encode -> D2H in slabs of

@@ -74,6 +74,7 @@ def _load():
         "zz_encode_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, u32, vp]),
         "zz_encode_stream_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, vp]),
         "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
+        "zz_verify_last_device": (i32, [vp, pu64, pu64, vp]),
         "zz_header": (i32, [i32, vp]),
         "zz_trailer": (i32, [i32, u32, u64, vp]),
         "zz_adler32": (u32, [u32, vp, u64]),
@@ -242,6 +243,14 @@ class Context:
         _check(lib.zz_encode_shard_device(self._h, self._ptr(src), n, halo, 1 if is_last else 0, self._ptr(dst), cap,
                                           ctypes.byref(out), ctypes.byref(cks), int(checksum), int(level), packet_size, st))
         return out.value, cks.value
+
+    def verify_last(self, stream=None):
+        """Inflates every packet of the last encode / encode_shard call's output on the device and compares with its
+        input (both tensors must still be alive): returns (bad packets, lowest bad packet or None)."""
+        bad, first = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_verify_last_device(self._h, ctypes.byref(bad), ctypes.byref(first), st))
+        return bad.value, (None if bad.value == 0 else first.value)
 
     def generate(self, kind, seed, first_byte, buf, n, stream=None):
         st = self._stream() if stream is None else stream

@@ -24,6 +24,7 @@
 #include "zz_stream2.h"
 #include "zz_compact.h"
 #include "zz_datagen.h"
+#include "zz_verify.h"
 
 using namespace zz;
 
@@ -59,6 +60,9 @@ struct zz_ctx {
     uint8_t* slab_out[2] = { nullptr, nullptr }; uint64_t slab_out_cap = 0;
     hipStream_t s_in = nullptr, s_enc = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_out[2] = { nullptr, nullptr };
+    // what the last packet-mode call did, for zz_verify_last_device
+    zz_verify_params last = {};  bool have_last = false;
+    unsigned long long* d_verify = nullptr;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_time = false;
@@ -122,7 +126,7 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
     (void)hipFree(c->l2_scratch);
     (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
-    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out);
+    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out); (void)hipFree(c->d_verify);
     for (int i = 0; i < 2; ++i) {
         (void)hipHostFree(c->pin_in[i]); (void)hipHostFree(c->pin_out[i]); (void)hipFree(c->slab_out[i]);
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
@@ -269,8 +273,40 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
     HIPCHK(hipMemcpyAsync(&kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *host_res = *c->h_res;
+    c->have_last = false;
     if (kerr) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
     if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    if (npk) {
+        zz_verify_params& v = c->last;
+        v.src = d_src; v.n = n; v.halo = halo; v.packet_size = P; v.npk = npk; v.last_is_final = last_is_final ? 1 : 0;
+        v.stream = d_dst + hl; v.stream_bytes = host_res->stream_bytes;
+        v.offsets = level ? c->offsets : nullptr; v.sizes = level ? c->sizes : nullptr;
+        v.l0_stride = (uint32_t)l0_packet_bytes(P, false);
+        c->have_last = true;
+    }
+    return ZZ_OK;
+}
+
+// inflate every packet of the stream the last packet-mode call on this context produced (device
+// entry points; its source and destination must still be in place) and compare with that call's input.
+extern "C" int zz_verify_last_device(zz_ctx* c, uint64_t* bad_packets, uint64_t* first_bad_packet, void* hip_stream)
+{
+    if (!c || !bad_packets) { set_err("null argument"); return ZZ_E_ARG; }
+    if (!c->have_last) { set_err("no packet-mode call to verify on this context"); return ZZ_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (!c->d_verify) HIPCHK(hipMalloc(&c->d_verify, 2 * sizeof(unsigned long long)));
+    const unsigned long long init[2] = { 0ull, ~0ull };
+    HIPCHK(hipMemcpyAsync(c->d_verify, init, sizeof init, hipMemcpyHostToDevice, st));
+    zz_verify_params v = c->last;
+    v.out = c->d_verify;
+    hipLaunchKernelGGL(k_verify_packets, dim3((v.npk + 63) / 64), dim3(64), 0, st, v);
+    HIPCHK(hipGetLastError());
+    unsigned long long res[2];
+    HIPCHK(hipMemcpyAsync(res, c->d_verify, sizeof res, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *bad_packets = res[0];
+    if (first_bad_packet) *first_bad_packet = res[1];
     return ZZ_OK;
 }
 
