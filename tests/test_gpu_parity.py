@@ -216,6 +216,31 @@ def test_device_inflate_self_check(gpu, corpus, lvl):
         assert gpu.ctx.verify_last() == (0, None), (kind, lvl)
 
 
+@pytest.mark.parametrize("kind,gib", [("text", 1), ("mix", 2), ("log", 1), ("random", 2)])
+def test_full_size_round_trip_on_device(gpu, kind, gib):
+    """BASELINE.json sizes (configs[1]: 1 GiB and beyond) at every level: every packet inflates on the device to its
+    input, and sizes/checksum trailer are consistent with the per-level invariants. Host zlib could not do this in
+    test time; sampled packets of the same generators are compared with the oracle in the 256 MiB test above."""
+    import torch
+    n = gib << 30
+    K = {"text": zz.GEN_TEXT, "mix": zz.GEN_MIX, "log": zz.GEN_LOG, "random": zz.GEN_RANDOM}[kind]
+    src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.ctx.generate(K, 0x5EED0002, 0, src, n)
+    dst = torch.empty(zz.bound(n, 1, 1, 32768), dtype=torch.uint8, device="cuda")
+    sizes = {}
+    for lvl in LEVELS:
+        cap = zz.bound(n, 1, lvl, 32768)
+        w = gpu.ctx.encode(src, n, dst, cap, 1, lvl)                    # gzip: CRC-32 + length trailer
+        assert gpu.ctx.verify_last() == (0, None), (kind, lvl)
+        tail = dst[w - 8:w].cpu().numpy().tobytes()
+        assert int.from_bytes(tail[4:], "little") == n & 0xFFFFFFFF
+        sizes[lvl] = w
+    assert sizes[2] == sizes[3]                                         # one code path in the reference (encoder.cpp:506-527)
+    assert sizes[0] == 10 + 8 + n + 10 * (n // 32768) - 5               # stored: 10 bytes per packet, 5 for the last
+    if kind != "random":
+        assert sizes[2] < sizes[1] < sizes[0]
+
+
 @pytest.mark.parametrize("fmt", [0, 1, 2])
 def test_host_slab_pipeline(gpu, oracle, corpus, fmt, monkeypatch):
     """Host buffers longer than one slab take the pipelined path (H2D -> encode -> D2H in slabs of
