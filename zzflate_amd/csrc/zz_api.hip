@@ -146,6 +146,15 @@ extern "C" uint64_t zz_ctx_workspace_bytes(const zz_ctx* c)
     if (!c) return 0;
     return c->slots_cap + c->npk_cap * (4 + 8 + sizeof(zz_cks)) + c->l2_scratch_cap + c->stage_in_cap + c->stage_out_cap;
 }
+// diagnostic (not part of the public header): workgroups of the level's encode kernel the runtime places on one CU
+extern "C" int zz_debug_occupancy(int level)
+{
+    int nb = -1;
+    if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
+    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2, ZZ_L2_THREADS, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
+    return nb;
+}
 // diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
 extern "C" int zz_debug_read_prof(zz_ctx* c, unsigned long long out[16])
 {
