@@ -63,6 +63,7 @@ struct zz_ctx {
     // what the last packet-mode call did, for zz_verify_last_device
     zz_verify_params last = {};  bool have_last = false;
     unsigned long long* d_verify = nullptr;
+    uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_time = false;
@@ -110,6 +111,7 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
     HIPCHK(hipMalloc(&c->d_res, sizeof(zz_result)));
     HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
     HIPCHK(hipMalloc(&c->d_err, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_work, sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
@@ -126,7 +128,7 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
     (void)hipFree(c->l2_scratch);
     (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
-    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out); (void)hipFree(c->d_verify);
+    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out); (void)hipFree(c->d_verify); (void)hipFree(c->d_work);
     for (int i = 0; i < 2; ++i) {
         (void)hipHostFree(c->pin_in[i]); (void)hipHostFree(c->pin_out[i]); (void)hipFree(c->slab_out[i]);
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
@@ -262,7 +264,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
             hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
         } else {
-            launch_level2(pp, c->l2_scratch, st);
+            launch_level2(pp, c->l2_scratch, c->d_work, st);
         }
         if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
         if (level != 0) {

@@ -918,6 +918,7 @@ __device__ __forceinline__ uint32_t l2_count_bits(const uint16_t* recs, const ui
 struct zz_l2_params {
     zz_packet_params pk;
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
+    uint32_t* work;        // packets handed out beyond the first gridDim.x (zero at launch)
 };
 
 #define ZZ_L2_LDS_BYTES (16384 + 560 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
@@ -968,7 +969,15 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
     uint32_t* tokens = (uint32_t*)my_scratch;                                   // matches in stream order
     uint16_t* recs = (uint16_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 4);            // records in stream order
 
-    for (uint32_t k = blockIdx.x; k < P.npk; k += gridDim.x) {
+    // Persistent workgroups: the first packet is the workgroup's index, every further one comes from a counter, so
+    // that packets of unequal cost (stored fallback vs. dynamic block) do not leave workgroups idle at the end.
+    auto next_packet = [&]() -> uint32_t {
+        __syncthreads();                                   // both wavefronts are done with the packet (and with LDS)
+        if (threadIdx.x == 0) ((uint32_t*)covw)[2] = gridDim.x + atomicAdd(Q.work, 1u);
+        __syncthreads();
+        return uniform(((uint32_t*)covw)[2]);
+    };
+    for (uint32_t k = blockIdx.x; k < P.npk; k = next_packet()) {
         const uint64_t off = (uint64_t)k * P.packet_size;
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
         const bool is_final = P.last_is_final && k == P.npk - 1;
@@ -1191,9 +1200,10 @@ static inline uint32_t l2_grid(uint32_t npk)
     const uint32_t resident = 256 * 9;      // CUs x workgroups the LDS budget admits
     return npk < resident ? npk : resident;
 }
-static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, hipStream_t st)
+static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st)
 {
-    zz_l2_params q; q.pk = pp; q.scratch = scratch;
+    zz_l2_params q; q.pk = pp; q.scratch = scratch; q.work = work;
+    (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_encode_l2, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
 }
 
