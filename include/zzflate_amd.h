@@ -70,7 +70,8 @@ double zz_ctx_last_kernel_ms(zz_ctx* ctx);
 uint64_t zz_bound(uint64_t n, int format, int level, uint32_t packet_size);
 
 /* ---- host-buffer entry points (drop-in for zzflate.h:17,19) -------------------------------------- */
-/* dest_len: in = capacity, out = bytes written or ~0. Copies through the device of the default context. */
+/* dest_len: in = capacity, out = bytes written or ~0. Goes through the device of the default context; buffers longer
+ * than one slab (64 MiB, env ZZFLATE_SLAB_MIB) are pipelined: H2D, encode and D2H of different slabs overlap. */
 int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, uint64_t n, const zz_config* cfg);
 /* callback(user, chunk, bytes) is invoked in order: header, stream chunks of <= 1,000,000 bytes
  * (outputbitstream.h:183), trailer. The callback's return value is ignored, as in the reference. */
