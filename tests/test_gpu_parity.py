@@ -36,6 +36,7 @@ def gpu():
             cap = zz.bound(n, 2, lvl, P)
             dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
             w, cks = ctx.encode_shard(buf.data_ptr() + off, n, dst, cap, halo, last, checksum, lvl, P)
+            assert ctx.verify_last() == (0, None)      # the device decoder follows distances into the halo
             return bytes(dst[:w].cpu().numpy().tobytes()), cks
         def stream(self, data, fmt, lvl):
             n = len(data)
