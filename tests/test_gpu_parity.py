@@ -186,6 +186,27 @@ def test_host_entry_points(gpu, oracle, corpus):
         zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, True), dest_capacity=100)
 
 
+def test_host_entry_points_from_several_threads(gpu, oracle, corpus):
+    """The reference is re-entrant for concurrent calls on distinct buffers: so are the drop-in entry
+    points (they serialise on the default context)."""
+    import threading
+    names = ["alice29.txt", "lcet10.txt", "kennedy.xls", "ptt5", "plrabn12.txt", "asyoulik.txt"]
+    want = {(nm, lvl): oracle.encode_packets(corpus[nm], 0, lvl) for nm in names for lvl in (1, 2)}
+    bad = []
+
+    def work(i):
+        for rep in range(3):
+            nm = names[(i + rep) % len(names)]
+            lvl = 1 + (i + rep) % 2
+            if zz.ZzFlateEncode(corpus[nm], zz.Config(zz.Format.Zlib, lvl, True)) != want[(nm, lvl)]:
+                bad.append((i, nm, lvl))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not bad
+
+
 @pytest.mark.parametrize("lvl", LEVELS)
 def test_device_inflate_self_check(gpu, corpus, lvl):
     """zz_verify_last_device: every packet of a stream inflates, on the device, to its input; a
