@@ -7,8 +7,11 @@ A *step* is one pass of the hot path over one batch of synthetic input that is a
 each rank compresses its own contiguous shard of packets (BASELINE.json configs[1]: 1 GiB of synthetic
 "enwik-style" text per GPU, level 1, zlib container, 32 KiB packets) into a device buffer, then -- for
 N > 1 -- the per-rank sizes/checksums are all-gathered and the compressed shards are gathered onto rank 0
-with one grouped RCCL send/recv (the "single gather over xGMI" of the north star). `value` is whole-job
-input GB/s = bytes all ranks compressed / max-over-ranks time. Scaling is weak (fixed work per GPU).
+with one grouped RCCL send/recv (the "single gather over xGMI" of the north star), straight into their final
+offsets. That gather is left in flight while the next step is encoded into a second pair of buffers (--chunks 1,
+default), or split into C pieces that travel while the next piece is encoded (--chunks C); the timed region
+ends only when every gather has landed. `value` is whole-job input GB/s = bytes all ranks compressed /
+max-over-ranks time. Scaling is weak (fixed work per GPU).
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
   "roofline":     the encode kernel's algorithmic bytes (input read once + compressed bytes written once,
@@ -16,6 +19,8 @@ Rank 0 prints ONE JSON line. Besides the contract fields it carries
                   against the 8 TB/s HBM peak; "traffic" comes from profiles/traffic.json when present
   "cpu_baseline": the unmodified reference (oracle/_ref, kind "reference") or, if that build is absent, the
                   oracle restatement (kind "port"), timed on this box's host cores on a bounded sample.
+  "check":        untimed validation of the last step: every packet inflated on the device and compared with its
+                  input (zz_verify_last_device, all ranks), plus a 64 MiB prefix through zlib on rank 0.
 The oracle is only the checker / baseline here, never the thing measured.
 """
 import argparse
