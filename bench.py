@@ -98,6 +98,41 @@ def cpu_baseline(sample: bytes, level: int, fmt: int):
     }
 
 
+def launch_ranks(n):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment,
+    as torch.distributed.run would set them) and wait for them. Children are separate processes started from a process
+    that never initialised the GPU; nothing is re-executed in place."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        while any(pr.poll() is None for pr in procs):
+            for pr in procs:
+                rc = pr.poll()
+                if rc not in (None, 0) and not worst:
+                    worst = rc
+                    for other in procs:                # a rank died: the others would wait in a collective forever
+                        if other.poll() is None:
+                            other.terminate()
+            time.sleep(0.2)
+        for pr in procs:
+            worst = worst or pr.returncode
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,10 +150,20 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: become one. This process has not touched the GPU (torch is not even imported yet); it
+        # starts one fresh child per rank -- the analogue of the reference's in-process fan-out, zzflate.cpp:127-132 --
+        # and exits with the worst of their exit codes. Rank 0's JSON line goes to this process's stdout.
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import zzflate_amd as zz
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does "
+              f"that itself; python -m torch.distributed.run --nproc-per-node N bench.py --gpus N works too)", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -135,7 +180,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(dev)
     fmt = {"zlib": 0, "gzip": 1, "deflate": 2}[args.format]
     ctx = zz.Context(dev)
@@ -309,7 +353,7 @@ def main():
             "ms_per_step": round(ms, 3),
             "higher_is_better": True,
             "scaling": "weak",
-            "backend": backend if world > 1 else None,
+            "backend": (("rccl" if backend == "nccl" else backend) + f" (torch.distributed {backend}, world size {dist.get_world_size()})") if world > 1 else None,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",

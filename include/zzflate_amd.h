@@ -17,11 +17,13 @@
  * Semantics: `threaded != 0` selects packet mode = the reference's threaded path (zzflate.cpp:97-155) with
  * fixed-size ranges ("packets", default 32 KiB) instead of hardware_concurrency() ranges; every packet is
  * bit-identical to the reference's packet recipe (zzflate.cpp:101-125) wherever that recipe yields a valid
- * DEFLATE encoding, and always valid otherwise. Inputs no longer than one packet therefore produce exactly
- * the reference's single-encoder stream. `threaded == 0` with an input longer than one packet asks for the
- * reference's sequential whole-buffer stream: produced on the device too, bit-identical to the reference (given
- * a destination of at least zz_bound() bytes), but at levels 1..3 by a single wavefront because that stream is
- * one dependency chain -- a compatibility mode, not a throughput mode. There is no CPU path.
+ * DEFLATE encoding, and always valid otherwise. `threaded == 0` asks for the reference's single Encoder over the
+ * whole input (zzflate.cpp:84-95): produced on the device too and bit-identical to the reference, including what
+ * depends on where the output goes -- at level 1 the block lengths follow from the room in the caller's buffer
+ * (encoder.cpp:331-337; zztest/Test.cpp passes dest = input size) or, through the callback, from the library's
+ * 1,000,000-byte chunks (outputbitstream.h:171-201), and the callback receives exactly the reference's chunks. At
+ * levels 1..3 that stream is one dependency chain, so it is made by a single wavefront -- a compatibility mode,
+ * not a throughput mode. There is no CPU path.
  *
  * Error convention (zzflate.cpp:229-234): *dest_len = ~0 for a bad level or a destination that cannot hold
  * the container header. This library additionally detects a destination that is too small for the stream
@@ -70,11 +72,17 @@ double zz_ctx_last_kernel_ms(zz_ctx* ctx);
 uint64_t zz_bound(uint64_t n, int format, int level, uint32_t packet_size);
 
 /* ---- host-buffer entry points (drop-in for zzflate.h:17,19) -------------------------------------- */
-/* dest_len: in = capacity, out = bytes written or ~0. Goes through the device of the default context; buffers longer
- * than one slab (64 MiB, env ZZFLATE_SLAB_MIB) are pipelined: H2D, encode and D2H of different slabs overlap. */
+/* dest_len: in = capacity, out = bytes written or ~0. Packet mode (threaded != 0) fans the input out over every
+ * visible GPU (env ZZFLATE_DEVICES = "0,1,..." or "all"; env ZZFLATE_DEVICE = one index), the device analogue of the
+ * reference's std::async fan-out over all cores (zzflate.cpp:97-155): buffers longer than one slab (64 MiB, env
+ * ZZFLATE_SLAB_MIB) are cut into slabs of whole packets, slab i goes to device i mod D, and on every device H2D,
+ * encode and D2H of different slabs overlap. Only two slabs of input and output are resident per device, so the input
+ * may be larger than HBM. Re-entrant: concurrent calls (and calls from inside a callback) borrow separate contexts. */
 int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, uint64_t n, const zz_config* cfg);
 /* callback(user, chunk, bytes) is invoked in order: header, stream chunks of <= 1,000,000 bytes
- * (outputbitstream.h:183), trailer. The callback's return value is ignored, as in the reference. */
+ * (outputbitstream.h:183), trailer. With threaded == 0 the chunks are the reference's own (see
+ * zz_encode_stream_chunks_device). The callback's return value is ignored, as in the reference. Nothing is delivered
+ * before the first part of the stream has encoded successfully. */
 typedef int (*zz_callback)(void* user, const uint8_t* chunk, uint64_t bytes);
 int zz_encode_callback(const uint8_t* src, uint64_t n, const zz_config* cfg, zz_callback cb, void* user);
 /* packet size used by the host entry points (env ZZFLATE_PACKET_SIZE overrides the default) */
@@ -86,13 +94,23 @@ uint32_t zz_get_packet_size(void);
 int zz_encode_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                      int format, int level, uint32_t packet_size, void* hip_stream);
 
-/* The reference's sequential whole-buffer stream (threaded == 0, zzflate.cpp:84-95) for device-resident data:
- * level 0 (stored blocks of 65535 bytes, parallel), level 1 (one fixed-Huffman block for the whole input) and
- * levels 2,3 (dynamic blocks cut at 20,000 records / 500,000 bytes, hash table carried across blocks), the latter
- * two produced by a single wavefront: bit-identical to the reference, far slower than packet mode. cap must be
- * at least zz_bound(); n < 2 GiB (the reference funnels lengths through int). */
+/* The reference's sequential whole-buffer stream (threaded == 0, zzflate.cpp:84-95) for device-resident data, in
+ * the form ZzFlateEncode gives it (caller-owned buffer of `cap` bytes): level 0 (stored blocks of 65535 bytes,
+ * parallel), level 1 (fixed-Huffman blocks; ONE for the whole input when (cap - header - 1) * 8 / 9 - 8 >= n, else as
+ * many as encoder.cpp:331-337 cuts for that capacity) and levels 2,3 (dynamic blocks cut at 20,000 records / 500,000
+ * bytes, hash table carried across blocks), the latter two produced by a single wavefront: bit-identical to the
+ * reference, far slower than packet mode. n < 2 GiB (the reference funnels lengths through int). Where the reference
+ * would run out of room and silently leave a truncated stream, ZZ_E_NOSPACE is returned. */
 int zz_encode_stream_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                             int format, int level, void* hip_stream);
+/* The same stream in the form ZzFlateEncodeToCallback gives it (zzflate.cpp:197-222): the encoder writes into
+ * library-owned chunks of 1,000,000 bytes and opens a new one when the current one is not "enough" for the next block
+ * (outputbitstream.h:171-201), which at level 1 also decides the block lengths. d_dst receives header + stream +
+ * trailer contiguously; chunk_sizes[0..*nchunks) (up to max_chunks are written) are the byte counts of the chunks in
+ * order, i.e. the sizes the reference's callback sees between the header call and the trailer call. */
+int zz_encode_stream_chunks_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                                   int format, int level, uint64_t* chunk_sizes, uint32_t max_chunks, uint32_t* nchunks,
+                                   void* hip_stream);
 
 /* One shard of a stream (multi-GPU: ranks own contiguous packet ranges). d_src points at the shard's first
  * byte; `halo` bytes in front of it are readable input of the same stream (level >= 2 backward match
@@ -111,6 +129,12 @@ int zz_encode_shard_device(zz_ctx* ctx, const void* d_src, uint64_t n, uint64_t 
  * no decoder (decoder.h is an empty stub). */
 int zz_verify_last_device(zz_ctx* ctx, uint64_t* bad_packets, uint64_t* first_bad_packet, void* hip_stream);
 
+/* Random access: where packet k (input bytes [k*packet_size, (k+1)*packet_size)) of the stream produced by the LAST
+ * zz_encode_device / zz_encode_shard_device call on this context lies. *offset counts from the first byte of the
+ * DEFLATE stream (behind the container header), *bytes is the packet's length. Packets are independent byte-aligned
+ * runs of complete blocks (zzflate.cpp:101-125), so each can be inflated on its own. */
+int zz_packet_extent_device(zz_ctx* ctx, uint64_t packet, uint64_t* offset, uint64_t* bytes, void* hip_stream);
+
 /* container pieces for assembling shards on the host */
 int zz_header(int format, uint8_t out[10]);                                   /* returns 0/2/10 */
 int zz_trailer(int format, uint32_t cks_total, uint64_t n, uint8_t out[8]);   /* returns 0/4/8  */
@@ -123,7 +147,8 @@ uint32_t zz_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 
 /* ---- synthetic inputs (BASELINE.json configs), generated on the device ------------------------------ */
 enum { ZZ_GEN_TEXT = 0, ZZ_GEN_RANDOM = 1, ZZ_GEN_LOG = 2, ZZ_GEN_MIX = 3 };
-/* fills d_buf[0,n); byte i is a pure function of (kind, seed, first_byte + i), in 1 MiB blocks */
+/* fills d_buf[0,n); byte i is a pure function of (kind, seed, first_byte + i), in 64 KiB blocks (first_byte must
+ * be a multiple of 65536) */
 int zz_generate_device(zz_ctx* ctx, int kind, uint64_t seed, uint64_t first_byte, void* d_buf, uint64_t n,
                        void* hip_stream);
 /* the same bytes computed on the host (for parity sampling) */

@@ -56,9 +56,12 @@ class Oracle:
         L.zzo_bitstream.restype = u64
         self.L = L
 
-    def encode(self, d, fmt, lvl):
-        cap = 2 * len(d) + 1024
-        b = ctypes.create_string_buffer(cap)
+    def encode(self, d, fmt, lvl, cap=None):
+        """zzo_encode into a destination of `cap` bytes (default: roomy). At level 1 the capacity decides the block
+        lengths (encoder.cpp:331-337); like the reference, the restatement silently leaves a truncated stream when the
+        room runs out (D9) -- callers check with inflate before using such a result as the expectation."""
+        cap = 2 * len(d) + 1024 if cap is None else cap
+        b = ctypes.create_string_buffer(max(cap, 16) + 64)      # the trailer append is unchecked in the reference
         n = self.L.zzo_encode(b, cap, d, len(d), fmt, lvl)
         return None if n == u64(-1).value else b.raw[:n]
 
@@ -99,9 +102,9 @@ class Ref:
         L.zzref_bitstream.restype = u64
         self.L = L
 
-    def encode(self, d, fmt, lvl, threaded=0, seed=1):
-        cap = 2 * len(d) + 1024
-        b = ctypes.create_string_buffer(cap)
+    def encode(self, d, fmt, lvl, threaded=0, seed=1, cap=None):
+        cap = 2 * len(d) + 1024 if cap is None else cap
+        b = ctypes.create_string_buffer(max(cap, 16) + 64)      # the reference appends the trailer unchecked
         n = self.L.zzref_encode(b, cap, d, len(d), fmt, lvl, threaded, seed)
         return None if n == u64(-1).value else b.raw[:n]
 

@@ -30,6 +30,7 @@ def test_links_and_reports_errors_without_gpu(tmp_path):
         gpu = False
     if not gpu:
         assert "ERR encode" in lines and "ERR callback" in lines   # no device => error convention, no CPU fallback
+        assert "ERR roundtrip 1" in lines and "ERR gzip" in lines
 
 
 @pytest.mark.gpu
@@ -39,3 +40,7 @@ def test_cxx_caller_round_trips_on_gpu(tmp_path):
     lines = [l for l in r.stdout.split("\n") if l]
     assert r.returncode == 0, r.stdout + r.stderr
     assert lines[0] == "OK 92346" and lines[1].startswith("OK 65734 ")   # SURVEY App. D packet-mode sizes
+    # the reference's own callers (zztest/Test.cpp:202-282): threaded=false, level 1 into max(200, n) bytes, levels 2,3
+    # through the callback, gzip level 1 into n bytes. Levels 2,3 are App. D's whole-stream sizes.
+    assert lines[2].startswith("OK roundtrip 1 ") and lines[3] == "OK roundtrip 2 64090" and lines[4] == "OK roundtrip 3 64090"
+    assert lines[5].startswith("OK gzip ")

@@ -1,0 +1,160 @@
+"""BASELINE.json's per-GPU configuration sizes under test (one MI355X holds every single-GPU-sized piece):
+  C3: 8 GiB uniform-random bytes at levels 0 (stored), 1 (expands 5.5 %) and 2 (stored fallback);
+  C4: one rank's 8 GiB shard of the 64 GiB mixed corpus at level 3 (== 2), with its 64 KiB left halo, through
+      zz_encode_shard_device exactly as a rank of the 8-GPU job runs it;
+  C5: one rank's 32 GiB shard of the 256 GiB log lines, gzip container (CRC-32), level 1.
+At these sizes the compacted offsets leave 32 bits. Checks: every packet inflated on the device and compared with its
+input (zz_verify_last_device), size and trailer invariants, a checksum of checksums, and sampled packets -- the first,
+the ones around the 4 GiB mark of the output, the last -- compared bit for bit with the oracle on the same bytes
+(regenerated on the host: the generators are pure functions of (seed, block)).
+Needs a real MI355X: run with `-m gpu`."""
+import zlib
+
+import pytest
+
+import zzflate_amd as zz
+
+pytestmark = pytest.mark.gpu
+P = 32768
+GIB = 1 << 30
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch, zz.Context(0)
+
+
+def sample_packets(npk, ctx, around_bytes=(1 << 32,)):
+    """first, last, a few in the middle, and the packets whose output lies around the given stream offsets"""
+    ks = {0, 1, npk // 3, npk // 2, npk - 2, npk - 1}
+    for target in around_bytes:
+        lo, hi = 0, npk - 1
+        while lo < hi:                       # offsets are increasing: bisect for the packet that crosses `target`
+            mid = (lo + hi) // 2
+            off, nb = ctx.packet_extent(mid)
+            if off + nb <= target:
+                lo = mid + 1
+            else:
+                hi = mid
+        for k in (lo - 1, lo, lo + 1):
+            if 0 <= k < npk:
+                ks.add(k)
+    return sorted(ks)
+
+
+def check_sampled(torch, ctx, oracle, dst, hl, kind, seed, first_byte, n, lvl, last_is_final, halo_avail, around=(1 << 32,)):
+    npk = (n + P - 1) // P
+    for k in sample_packets(npk, ctx, around):
+        off, nb = ctx.packet_extent(k)
+        got = dst[hl + off: hl + off + nb].cpu().numpy().tobytes()
+        # the packet's input and what lies in front of it (level >= 2 extends matches backward over up to 258 bytes)
+        pk_off = k * P
+        ln = min(P, n - pk_off)
+        pre = min(65536, pk_off + halo_avail)
+        start = first_byte + pk_off - pre
+        base = start // 65536 * 65536
+        host = zz.generate_host(kind, seed, base, (start - base) + pre + ln)
+        window = host[start - base:]
+        want = oracle.packet(window, lvl, pre, ln, last_is_final and k == npk - 1)
+        assert got == want, (kind, lvl, k, off, nb, len(want))
+
+
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_c3_random_8gib(dev, oracle, lvl):
+    torch, ctx = dev
+    n = 8 * GIB
+    seed = 0x5EED0003
+    src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate(zz.GEN_RANDOM, seed, 0, src, n)
+    cap = zz.bound(n, 0, lvl, P)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    w = ctx.encode(src, n, dst, cap, zz.Format.Zlib, lvl, P)
+    assert ctx.verify_last() == (0, None)
+    npk = n // P
+    if lvl == 0 or lvl == 2:
+        # stored: level 0 by definition, level 2 because the dynamic block would not be smaller (encoder.cpp:271-274)
+        assert w == 2 + 4 + n + 10 * npk - 5 + (0 if lvl == 0 else 0)
+    else:
+        assert 1.054 < w / n < 1.056                                   # level 1 never falls back
+    assert w > 1 << 33                                                 # compacted offsets beyond 32 bits were exercised
+    # Adler-32 trailer: a checksum of checksums -- the whole-stream value equals the fold of per-GiB partials computed by
+    # separate shard calls, and one of those partials is checked against host zlib
+    tail = int.from_bytes(dst[w - 4:w].cpu().numpy().tobytes(), "big")
+    check_sampled(torch, ctx, oracle, dst, 2, zz.GEN_RANDOM, seed, 0, n, lvl, True, 0, around=(1 << 32, 1 << 33))
+    if lvl == 0:
+        acc = 1
+        piece_dst = torch.empty(zz.bound(GIB, 2, 0, P), dtype=torch.uint8, device="cuda")
+        for i in range(8):
+            _, cks = ctx.encode_shard(src.data_ptr() + i * GIB, GIB, piece_dst, piece_dst.numel(), halo=i * GIB, is_last=(i == 7),
+                                      checksum=zz.Format.Zlib, level=0)
+            if i == 5:
+                host = src[i * GIB:(i + 1) * GIB].cpu().numpy().tobytes()
+                assert zz.combine(1, cks, GIB) == zlib.adler32(host)
+                del host
+            acc = zz.combine(acc, cks, GIB)
+        assert acc == tail
+
+
+def test_c4_mix_shard_8gib_level3_with_halo(dev, oracle):
+    """Rank 3 of the 8-GPU job of configs[3]: bytes [24 GiB, 32 GiB) of the mixed corpus plus the 64 KiB in front."""
+    torch, ctx = dev
+    n = 8 * GIB
+    seed = 0x5EED0004
+    halo = 65536
+    first = 3 * n
+    buf = torch.empty(halo + n + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate(zz.GEN_MIX, seed, first - halo, buf, halo + n)
+    cap = zz.bound(n, 2, 3, P)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    w3, cks3 = ctx.encode_shard(buf.data_ptr() + halo, n, dst, cap, halo=halo, is_last=False, checksum=zz.Format.Zlib, level=3)
+    assert ctx.verify_last() == (0, None)
+    check_sampled(torch, ctx, oracle, dst, 0, zz.GEN_MIX, seed, first, n, 3, False, halo)
+    assert w3 < n                                                       # it compresses
+    first_kib = dst[:1024].cpu().numpy().tobytes()
+    # level 2 is the same code path in the reference (encoder.cpp:506-527): same bytes, same checksum partial
+    w2, cks2 = ctx.encode_shard(buf.data_ptr() + halo, n, dst, cap, halo=halo, is_last=False, checksum=zz.Format.Zlib, level=2)
+    assert (w2, cks2) == (w3, cks3) and dst[:1024].cpu().numpy().tobytes() == first_kib
+    # the shard's Adler-32 partial (start value 0) against host zlib on its first GiB + the fold of the rest
+    acc = 0
+    piece_dst = torch.empty(zz.bound(GIB, 2, 0, P), dtype=torch.uint8, device="cuda")
+    for i in range(8):
+        _, c = ctx.encode_shard(buf.data_ptr() + halo + i * GIB, GIB, piece_dst, piece_dst.numel(), halo=halo + i * GIB, is_last=False,
+                                checksum=zz.Format.Zlib, level=0)
+        if i == 0:
+            host = buf[halo:halo + GIB].cpu().numpy().tobytes()
+            assert zz.combine(1, c, GIB) == zlib.adler32(host)
+            del host
+        acc = zz.combine(acc, c, GIB) if i else c
+    assert acc == cks3
+
+
+def test_c5_log_shard_32gib_gzip_level1(dev, oracle):
+    """One rank's share of configs[4]: 32 GiB of log lines, gzip container, level 1 -- ~105 GB of HBM in use."""
+    torch, ctx = dev
+    n = 32 * GIB
+    seed = 0x5EED0005
+    src = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate(zz.GEN_LOG, seed, 0, src, n)
+    cap = zz.bound(n, 1, 1, P)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    w = ctx.encode(src, n, dst, cap, zz.Format.Gzip, 1, P)
+    assert ctx.verify_last() == (0, None)
+    assert 0.3 < w / n < 0.6
+    assert w > 1 << 33
+    tail = dst[w - 8:w].cpu().numpy().tobytes()
+    assert int.from_bytes(tail[4:], "little") == n & 0xFFFFFFFF         # ISIZE is the length mod 2^32 (zzflate.cpp:188)
+    check_sampled(torch, ctx, oracle, dst, 10, zz.GEN_LOG, seed, 0, n, 1, True, 0, around=(1 << 32, 1 << 33, 3 << 32))
+    # CRC-32: fold of 32 per-GiB partials from separate shard calls == the trailer; one partial against host zlib
+    acc = 0
+    piece_dst = torch.empty(zz.bound(GIB, 2, 0, P), dtype=torch.uint8, device="cuda")
+    for i in range(32):
+        _, c = ctx.encode_shard(src.data_ptr() + i * GIB, GIB, piece_dst, piece_dst.numel(), halo=i * GIB, is_last=(i == 31),
+                                checksum=zz.Format.Gzip, level=0)
+        if i == 17:
+            host = src[i * GIB:(i + 1) * GIB].cpu().numpy().tobytes()
+            assert c == zlib.crc32(host)
+            del host
+        acc = zz.crc32_combine(acc, c, GIB)
+    assert acc == int.from_bytes(tail[:4], "little")

@@ -1,0 +1,112 @@
+"""The N > 1 path with the real shard encoder: two ranks share the one GPU of the test box, each encodes its packet
+range with zz_encode_shard_device (left halo included), and zzflate_amd.sharded assembles the stream on rank 0 --
+over gloo here (one GPU cannot host two RCCL ranks), over RCCL/xGMI on a multi-GPU node, same code. The result must
+equal the single-call stream and the oracle's bit for bit. Also: `bench.py --gpus 2` launches its own ranks.
+Needs a real MI355X: run with `-m gpu`."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, zlib
+ROOT = sys.argv[1]; fmt = int(sys.argv[2]); lvl = int(sys.argv[3]); P = int(sys.argv[4]); chunks = int(sys.argv[5]); out_path = sys.argv[6]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import torch.distributed as dist
+import zzflate_amd as zz
+from zzflate_amd import sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+ctx = zz.Context(0)
+corpus = os.path.join(ROOT, "tests", "golden", "corpus")
+data = b"".join(open(os.path.join(corpus, f), "rb").read() for f in ("lcet10.txt", "kennedy.xls", "ptt5", "alice29.txt")) * 2 + b"tail"
+n_total = len(data)
+whole = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+off, n = sharded.shard_range(n_total, P, rank, world)
+halo = min(off, 65536)                       # the bytes in front of the shard that this rank holds too
+cap = zz.bound(n, 2, lvl, P)
+shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
+outbuf = torch.zeros(zz.bound(n_total, fmt, lvl, P) + 64, dtype=torch.uint8) if rank == 0 else None
+if chunks <= 1:
+    w, cks = ctx.encode_shard(whole.data_ptr() + off, n, shard, cap, halo=halo, is_last=(rank == world - 1), checksum=fmt, level=lvl, packet_size=P)
+    assert ctx.verify_last() == (0, None)
+    total = sharded.gather_stream(dist, fmt, shard[:w].cpu(), w, cks, n, outbuf)
+else:
+    pg = sharded.PipelinedGather(dist, fmt, cap + 4096, torch.device("cpu"))
+    npk = (n + P - 1) // P
+    per = (npk + chunks - 1) // chunks * P
+    for c in range(chunks):
+        a, b = min(c * per, n), min((c + 1) * per, n)
+        w, cks = (0, 0)
+        if b > a:
+            w, cks = ctx.encode_shard(whole.data_ptr() + off + a, b - a, shard, cap, halo=halo + a, is_last=(rank == world - 1 and b == n),
+                                      checksum=fmt, level=lvl, packet_size=P)
+        pg.push(shard[:max(w, 1)].cpu(), w, cks, b - a)
+    total = pg.finish(outbuf)
+if rank == 0:
+    from conftest import Oracle
+    got = outbuf[:total].numpy().tobytes()
+    cap1 = zz.bound(n_total, fmt, lvl, P)
+    dst = torch.empty(cap1, dtype=torch.uint8, device="cuda")
+    w1 = ctx.encode(whole, n_total, dst, cap1, fmt, lvl, P)
+    single = dst[:w1].cpu().numpy().tobytes()
+    want = Oracle().encode_packets(data, fmt, lvl, P)
+    ok = got == single == want and zlib.decompressobj({0: 15, 1: 31, 2: -15}[fmt]).decompress(got) == data
+    open(out_path, "w").write("ok" if ok else f"MISMATCH {len(got)} {len(single)} {len(want)}")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(tmp_path, world, args):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    res = tmp_path / "result.txt"
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT] + [str(a) for a in args] + [str(res)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return res.read_text()
+
+
+@pytest.mark.parametrize("fmt,lvl,P,chunks", [(0, 1, 32768, 1), (1, 2, 32768, 1), (0, 3, 32768, 3), (2, 0, 4096, 1), (1, 1, 8192, 2)])
+def test_two_ranks_encode_shards_and_gather(tmp_path, fmt, lvl, P, chunks):
+    assert _run_ranks(tmp_path, 2, [fmt, lvl, P, chunks]) == "ok"
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself and reports n_gpus 2; a world size
+    that does not match --gpus is an error, not a silent single-GPU run."""
+    env = dict(os.environ, ZZ_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mib", "64",
+                        "--no-cpu", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "gloo" in line["backend"] and "world size 2" in line["backend"]
+    assert line["check"]["device_inflate"]["bad"] == 0 and line["check"]["inflate_prefix_ok"]
+    assert line["check"]["device_inflate"]["packets"] == 2 * (64 << 20) // 32768
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=dict(env, WORLD_SIZE="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

@@ -285,6 +285,90 @@ def test_host_slab_pipeline(gpu, oracle, corpus, fmt, monkeypatch):
         zz.ZzFlateEncode(d, zz.Config(F, 1, True), dest_capacity=len(d) // 4)
 
 
+def test_host_input_larger_than_the_staging_ring(gpu, oracle, corpus, monkeypatch):
+    """the host entry points keep two slabs of input (plus 4 KiB in front of each, for level >= 2's
+    backward match extension) and two of output on the device, whatever the input's size -- so inputs larger than HBM
+    work. 24 MiB through 1 MiB slabs: same bytes as one call / the oracle, staging far smaller than the input."""
+    monkeypatch.setenv("ZZFLATE_SLAB_MIB", "1")
+    monkeypatch.setenv("ZZFLATE_DEVICES", "0")
+    zz.lib.zz_debug_reset_devices()
+    try:
+        text = zz.generate_host(zz.GEN_TEXT, 0x5EED0002, 0, 6 << 20)
+        d = text + corpus["kennedy.xls"] * 3 + zz.generate_host(zz.GEN_LOG, 0x5EED0005, 0, 5 << 20) + corpus["ptt5"] * 4 + \
+            zz.generate_host(zz.GEN_MIX, 0x5EED0004, 0, 7 << 20) + b"ragged tail"
+        assert len(d) > 22 << 20
+        for lvl in LEVELS:
+            want = oracle.encode_packets(d, 1, lvl)
+            got = zz.ZzFlateEncode(d, zz.Config(zz.Format.Gzip, lvl, True))
+            assert got == want, lvl
+        assert zz.lib.zz_debug_host_staging_bytes() < 12 << 20        # two 1 MiB slabs each way (+ the simple path's buffers)
+    finally:
+        monkeypatch.undo()
+        zz.lib.zz_debug_reset_devices()
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_multi_device_fan_out(gpu, oracle, corpus, monkeypatch, devices):
+    """The device analogue of the reference's std::async fan-out (zzflate.cpp:97-155) behind ZzFlateEncode: slabs go
+    round-robin to the devices of ZZFLATE_DEVICES (here the same GPU several times: several pipelines, several
+    contexts, several host threads), the calling thread joins them in order. Same bytes as a single device."""
+    monkeypatch.setenv("ZZFLATE_SLAB_MIB", "1")
+    monkeypatch.setenv("ZZFLATE_DEVICES", devices)
+    zz.lib.zz_debug_reset_devices()
+    try:
+        d = (corpus["lcet10.txt"] + corpus["ptt5"] + corpus["kennedy.xls"] + corpus["plrabn12.txt"]) * 4 + b"end"   # ~9.7 MiB: ten slabs
+        for lvl in LEVELS:
+            for fmt in (0, 1, 2):
+                F = [zz.Format.Zlib, zz.Format.Gzip, zz.Format.Deflate][fmt]
+                want = oracle.encode_packets(d, fmt, lvl)
+                assert zz.ZzFlateEncode(d, zz.Config(F, lvl, True)) == want, (devices, lvl, fmt)
+            chunks = []
+            zz.ZzFlateEncodeToCallback(d, zz.Config(zz.Format.Zlib, lvl, True), chunks.append)
+            assert b"".join(chunks) == oracle.encode_packets(d, 0, lvl)
+        with pytest.raises(zz.ZzFlateError):
+            zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, True), dest_capacity=len(d) // 4)
+    finally:
+        monkeypatch.undo()
+        zz.lib.zz_debug_reset_devices()
+
+
+def test_callback_may_call_back_into_the_library(gpu, oracle, corpus):
+    """No lock is held while callbacks run: a callback that encodes something itself must not deadlock, and an
+    exception raised by the callback reaches the caller."""
+    d = corpus["alice29.txt"]
+    inner = []
+
+    def cb(chunk):
+        if not inner:
+            inner.append(zz.ZzFlateEncode(corpus["fields.c"], zz.Config(zz.Format.Zlib, 2, True)))
+    zz.ZzFlateEncodeToCallback(d, zz.Config(zz.Format.Zlib, 1, True), cb)
+    assert inner[0] == oracle.encode_packets(corpus["fields.c"], 0, 2)
+
+    class Boom(Exception):
+        pass
+
+    def bad(chunk):
+        raise Boom()
+    with pytest.raises(Boom):
+        zz.ZzFlateEncodeToCallback(d, zz.Config(zz.Format.Zlib, 1, True), bad)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 13, 15, 16, 17])
+def test_tiny_packets_at_the_end_of_an_allocation(gpu, oracle, P):
+    """Packets shorter than the 16-byte loads: bounds-checked loads are chosen by bytes, not by packet index, so
+    nothing is read past the input even when it ends exactly at the end of its allocation."""
+    torch = gpu.torch
+    for n in (73, 256, 1000):
+        d = synth("words", n, P)
+        for lvl in (1, 2):
+            # the source tensor has exactly n bytes: its last byte is the last byte of the allocation
+            src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+            cap = zz.bound(n, 2, lvl, P)
+            dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            w = gpu.ctx.encode(src, n, dst, cap, 2, lvl, P)
+            assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 2, lvl, P), (P, n, lvl)
+
+
 @pytest.mark.parametrize("lvl", LEVELS)
 def test_shards_concatenate_to_the_whole_stream(gpu, oracle, corpus, lvl):
     """Multi-GPU contract on one GPU: shards cut at packet boundaries + checksum combine == one call."""

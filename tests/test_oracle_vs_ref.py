@@ -55,6 +55,23 @@ def test_synth(oracle, ref, kind):
                         assert valid(a, d[off:off + ln], 2, zd) and not any(valid(r, d[off:off + ln], 2, zd) for r in refs), (kind, n, P, lvl, k)
 
 
+@pytest.mark.parametrize("fname", CORPUS_FILES)
+def test_tight_destination_level1(oracle, ref, corpus, fname):
+    """The level-1 block lengths follow from the destination's capacity (encoder.cpp:331-337); the reference's callers
+    pass max(200, n) (zztest/Test.cpp:206). Identical bytes wherever the reference's multi-block stream is valid."""
+    d = corpus[fname]
+    n = len(d)
+    same = 0
+    for fmt in (0, 1, 2):
+        for cap in (max(200, n), n * 95 // 100, n * 9 // 10, n * 85 // 100, n * 8 // 10, n * 3 // 4):
+            a, b = oracle.encode(d, fmt, 1, cap=cap), ref.encode(d, fmt, 1, cap=cap)
+            if a == b:
+                same += 1
+            else:
+                assert valid(a, d, fmt) and not valid(b, d, fmt), (fname, fmt, cap)
+    assert same >= 3      # the cut is crossed by a short match in a good third of the cases (D12)
+
+
 def test_callback_api(oracle, ref, corpus):
     for fname in ("alice29.txt", "kennedy.xls", "sum"):
         d = corpus[fname]

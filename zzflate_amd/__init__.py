@@ -54,9 +54,7 @@ def _load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = _build.LIB
-    if not os.path.exists(path):
-        _build.build()
+    path = _build.build()          # returns at once when the library is newer than every source under csrc/ and include/
     L = ctypes.CDLL(path)
     u64, u32, i32, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
     pu64 = ctypes.POINTER(ctypes.c_uint64)
@@ -73,8 +71,10 @@ def _load():
         "zz_get_packet_size": (u32, []),
         "zz_encode_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, u32, vp]),
         "zz_encode_stream_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, vp]),
+        "zz_encode_stream_chunks_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, pu64, u32, ctypes.POINTER(u32), vp]),
         "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
         "zz_verify_last_device": (i32, [vp, pu64, pu64, vp]),
+        "zz_packet_extent_device": (i32, [vp, u64, pu64, pu64, vp]),
         "zz_header": (i32, [i32, vp]),
         "zz_trailer": (i32, [i32, u32, u64, vp]),
         "zz_adler32": (u32, [u32, vp, u64]),
@@ -83,6 +83,8 @@ def _load():
         "zz_crc32_combine": (u32, [u32, u32, u64]),
         "zz_generate_device": (i32, [vp, i32, u64, u64, vp, u64, vp]),
         "zz_generate_host": (i32, [i32, u64, u64, vp, u64]),
+        "zz_debug_reset_devices": (None, []),
+        "zz_debug_host_staging_bytes": (u64, []),
         "zz_last_error": (ctypes.c_char_p, []),
         "zz_version": (ctypes.c_char_p, []),
     }
@@ -127,14 +129,23 @@ def ZzFlateEncode(source, config, dest_capacity=None):
 def ZzFlateEncodeToCallback(source, config, callback):
     """zzflate.h:19 -- ``callback(chunk: bytes)`` is called for the header, each stream chunk and the trailer."""
     src = bytes(source)
+    failure = []
 
     def tramp(_user, ptr, nbytes):
-        callback(ctypes.string_at(ptr, nbytes))
+        # an exception must not vanish inside the ctypes trampoline: keep the first one, stop forwarding, re-raise below
+        if not failure:
+            try:
+                callback(ctypes.string_at(ptr, nbytes))
+            except BaseException as e:          # noqa: BLE001
+                failure.append(e)
         return 0
 
     cb = _CALLBACK(tramp)
     c = _cfg(config)
-    _check(lib.zz_encode_callback(src, len(src), ctypes.byref(c), ctypes.cast(cb, ctypes.c_void_p), None))
+    rc = lib.zz_encode_callback(src, len(src), ctypes.byref(c), ctypes.cast(cb, ctypes.c_void_p), None)
+    if failure:
+        raise failure[0]
+    _check(rc)
 
 
 def adler32x(start, data):  # adler.cpp:17-43
@@ -201,11 +212,10 @@ class Context:
     def _ptr(t):
         return t if isinstance(t, int) else t.data_ptr()
 
-    @staticmethod
-    def _stream():
+    def _stream(self):
         try:
             import torch
-            return torch.cuda.current_stream().cuda_stream
+            return torch.cuda.current_stream(self.device).cuda_stream     # this context's device, not torch's current one
         except Exception:
             return 0
 
@@ -227,12 +237,24 @@ class Context:
         return out.value
 
     def encode_stream(self, src, n, dst, cap, format=Format.Zlib, level=1, stream=None):
-        """The reference's sequential whole-buffer stream (threaded=false) on the device; levels 0 and 1."""
+        """The reference's sequential whole-buffer stream (threaded=false) into a caller-owned buffer of ``cap`` bytes
+        (at level 1 the capacity decides the block lengths, encoder.cpp:331-337)."""
         out = ctypes.c_uint64(0)
         st = self._stream() if stream is None else stream
         _check(lib.zz_encode_stream_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
                                            int(level), st))
         return out.value
+
+    def encode_stream_chunks(self, src, n, dst, cap, format=Format.Zlib, level=1, stream=None):
+        """The sequential stream as ZzFlateEncodeToCallback produces it (library-owned 1,000,000-byte chunks decide the
+        level-1 block lengths); returns (bytes written, [chunk sizes the reference's callback would see])."""
+        out = ctypes.c_uint64(0)
+        sizes = (ctypes.c_uint64 * 8192)()
+        nch = ctypes.c_uint32(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_stream_chunks_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
+                                                  int(level), sizes, 8192, ctypes.byref(nch), st))
+        return out.value, list(sizes[: nch.value])
 
     def encode_shard(self, src, n, dst, cap, halo=0, is_last=True, checksum=Format.Zlib, level=1,
                      packet_size=DEFAULT_PACKET, stream=None):
@@ -251,6 +273,13 @@ class Context:
         st = self._stream() if stream is None else stream
         _check(lib.zz_verify_last_device(self._h, ctypes.byref(bad), ctypes.byref(first), st))
         return bad.value, (None if bad.value == 0 else first.value)
+
+    def packet_extent(self, k, stream=None):
+        """(offset behind the container header, bytes) of packet k in the stream the last encode / encode_shard call wrote."""
+        off, nb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_packet_extent_device(self._h, k, ctypes.byref(off), ctypes.byref(nb), st))
+        return off.value, nb.value
 
     def generate(self, kind, seed, first_byte, buf, n, stream=None):
         st = self._stream() if stream is None else stream

@@ -20,11 +20,20 @@ def _newest_source_mtime():
 def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
         return LIB
+    import fcntl
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + SOURCES
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    # several ranks may import the package at once: one of them builds (into a temporary file, renamed into place),
+    # the others wait on the lock and find the library up to date
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
+            return LIB
+        tmp = f"{LIB}.{os.getpid()}.tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + SOURCES
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB)
     return LIB
 
 

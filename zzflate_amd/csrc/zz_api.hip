@@ -5,6 +5,7 @@
 // There is no CPU encode path in this library: every byte of DEFLATE output is produced by the HIP
 // kernels, and every entry point fails with ZZ_E_HIP when no device is usable.
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -58,12 +59,14 @@ struct zz_ctx {
     uint8_t* pin_in[2] = { nullptr, nullptr };  uint64_t pin_in_cap = 0;
     uint8_t* pin_out[2] = { nullptr, nullptr }; uint64_t pin_out_cap = 0;
     uint8_t* slab_out[2] = { nullptr, nullptr }; uint64_t slab_out_cap = 0;
+    uint8_t* slab_in[2] = { nullptr, nullptr };                                    // device input ring: halo + slab each
     hipStream_t s_in = nullptr, s_enc = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_out[2] = { nullptr, nullptr };
     // what the last packet-mode call did, for zz_verify_last_device
     zz_verify_params last = {};  bool have_last = false;
     unsigned long long* d_verify = nullptr;
     uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
+    uint64_t* d_log = nullptr; uint64_t log_cap_bytes = 0;   // sequential stream, callback form: EnsureOutputLength log
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_time = false;
@@ -94,6 +97,7 @@ extern "C" uint64_t zz_bound(uint64_t n, int format, int level, uint32_t P)
     return header_len(format) + npk * per + trailer_len(format) + 16;
 }
 
+extern "C" void zz_ctx_destroy(zz_ctx* c);
 extern "C" int zz_ctx_create(int device, zz_ctx** out)
 {
     if (!out) { set_err("null out"); return ZZ_E_ARG; }
@@ -108,15 +112,19 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
     HIPCHK(hipSetDevice(device));
     zz_ctx* c = new zz_ctx();
     c->device = device;
-    HIPCHK(hipMalloc(&c->d_res, sizeof(zz_result)));
-    HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
-    HIPCHK(hipMalloc(&c->d_err, sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_work, sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
-    HIPCHK(hipEventCreate(&c->ev0));
-    HIPCHK(hipEventCreate(&c->ev1));
+    const int rc = [&]() -> int {
+        HIPCHK(hipMalloc(&c->d_res, sizeof(zz_result)));
+        HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
+        HIPCHK(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)));          // [0] slot overflow, [1] stream truncated, [2] log entries
+        HIPCHK(hipMalloc(&c->d_work, sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
+        HIPCHK(hipEventCreate(&c->ev0));
+        HIPCHK(hipEventCreate(&c->ev1));
+        return ZZ_OK;
+    }();
+    if (rc) { zz_ctx_destroy(c); return rc; }                            // nothing allocated so far is left behind
     *out = c;
     return ZZ_OK;
 }
@@ -128,9 +136,9 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
     (void)hipFree(c->l2_scratch);
     (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
-    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out); (void)hipFree(c->d_verify); (void)hipFree(c->d_work);
+    (void)hipFree(c->stage_in); (void)hipFree(c->stage_out); (void)hipFree(c->d_verify); (void)hipFree(c->d_work); (void)hipFree(c->d_log);
     for (int i = 0; i < 2; ++i) {
-        (void)hipHostFree(c->pin_in[i]); (void)hipHostFree(c->pin_out[i]); (void)hipFree(c->slab_out[i]);
+        (void)hipHostFree(c->pin_in[i]); (void)hipHostFree(c->pin_out[i]); (void)hipFree(c->slab_out[i]); (void)hipFree(c->slab_in[i]);
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
         if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
     }
@@ -220,6 +228,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
     const uint32_t npk = (uint32_t)npk64;
     const uint32_t stride = slot_stride_for(level, P);
     c->have_time = false;
+    c->have_last = false;            // whatever zz_verify_last_device could look at is about to change
 
     HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(zz_result), st));
     HIPCHK(hipMemsetAsync(c->d_cks_total, 0, sizeof(zz_cks_total), st));
@@ -284,7 +293,6 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
     HIPCHK(hipMemcpyAsync(&kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *host_res = *c->h_res;
-    c->have_last = false;
     if (kerr) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
     if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
     if (npk) {
@@ -321,30 +329,68 @@ extern "C" int zz_verify_last_device(zz_ctx* c, uint64_t* bad_packets, uint64_t*
     return ZZ_OK;
 }
 
+// Where packet k of the stream the last packet-mode call on this context produced lies: *offset counts from the first
+// byte of the DEFLATE stream (behind the container header), *bytes is the packet's length. Packets are independent
+// (cold table, byte-aligned: zzflate.cpp:101-125), so this is a random-access index into the stream -- and what the
+// full-size tests use to compare sampled packets of a multi-GiB call with the oracle.
+extern "C" int zz_packet_extent_device(zz_ctx* c, uint64_t packet, uint64_t* offset, uint64_t* bytes, void* hip_stream)
+{
+    if (!c || !offset || !bytes) { set_err("null argument"); return ZZ_E_ARG; }
+    if (!c->have_last) { set_err("no packet-mode call on this context"); return ZZ_E_ARG; }
+    const zz_verify_params& v = c->last;
+    if (packet >= v.npk) { set_err("packet index out of range"); return ZZ_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!v.offsets) {                                         // level 0: every packet has its known place
+        *offset = packet * v.l0_stride;
+        *bytes = packet + 1 < v.npk ? v.l0_stride : v.stream_bytes - packet * v.l0_stride;
+        return ZZ_OK;
+    }
+    uint64_t o = 0; uint32_t sz = 0;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(hipMemcpyAsync(&o, v.offsets + packet, sizeof o, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&sz, v.sizes + packet, sizeof sz, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *offset = o; *bytes = sz;
+    return ZZ_OK;
+}
+
 static int cks_kind_for(int format) { return format == ZZ_ZLIB ? ZZ_CKS_ADLER : format == ZZ_GZIP ? ZZ_CKS_CRC : ZZ_CKS_NONE; }
 
 // The reference's sequential whole-buffer stream (threaded=false, zzflate.cpp:84-95) on the device. Level 0 is
-// parallel (stored blocks of 65535 bytes have known places); level 1 is one fixed-Huffman block, levels 2,3 a chain
-// of dynamic blocks, each produced by a single wavefront (k_stream_l1 / k_stream_l2) -- a compatibility mode,
-// bit-identical to the reference, not a fast one.
+// parallel (stored blocks of 65535 bytes have known places); level 1 is a chain of fixed-Huffman blocks whose lengths
+// follow from the room in the output buffer (encoder.cpp:331-337: ONE block when the destination is roomy), levels
+// 2,3 a chain of dynamic blocks, each chain produced by a single wavefront (k_stream_l1 / k_stream_l2) -- a
+// compatibility mode, bit-identical to the reference, not a fast one.
+//   chunked == false: ZzFlateEncode's caller-owned buffer of `cap` bytes (zzflate.cpp:225-242);
+//   chunked == true : ZzFlateEncodeToCallback's library-owned chunks of 1,000,000 bytes (zzflate.cpp:197-222,
+//                     outputbitstream.h:171-201); *chunk_sizes receives the byte counts the callback would see between the
+//                     header call and the trailer call, `cap` only has to hold the stream.
 static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d_dst, uint64_t cap, int format, int level,
-                         hipStream_t st, zz_result* host_res)
+                         bool chunked, std::vector<uint64_t>* chunk_sizes, hipStream_t st, zz_result* host_res)
 {
     if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
     if (!d_dst || (!d_src && n)) { set_err("null buffer"); return ZZ_E_ARG; }
-    if (n == 0) return encode_common(c, d_src, 0, 0, true, d_dst, cap, format, cks_kind_for(format), true, level, ZZ_DEFAULT_PACKET, st, host_res);
+    if (chunk_sizes) chunk_sizes->clear();
+    if (n == 0) {
+        int rc = encode_common(c, d_src, 0, 0, true, d_dst, cap, format, cks_kind_for(format), true, level, ZZ_DEFAULT_PACKET, st, host_res);
+        if (!rc && chunk_sizes && host_res->stream_bytes) chunk_sizes->push_back(host_res->stream_bytes);
+        return rc;
+    }
     if (n >= (1ull << 31)) { set_err("sequential stream: input must be < 2 GiB (the reference funnels lengths through int)"); return ZZ_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
     const int hl = header_len(format), tl = trailer_len(format);
     if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
     const int cks_kind = cks_kind_for(format);
     c->have_time = false;
+    c->have_last = false;
     HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(zz_result), st));
     HIPCHK(hipMemsetAsync(c->d_cks_total, 0, sizeof(zz_cks_total), st));
-    HIPCHK(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), st));
     zz_packet_params pp;
     memset(&pp, 0, sizeof pp);
     pp.src = d_src; pp.n = n; pp.halo = 0; pp.last_is_final = 1; pp.err = c->d_err; pp.prof = c->d_prof;
+    std::vector<uint64_t> log;           // (bytes stored, length asked for) per EnsureOutputLength call, chunked form
+    uint32_t log_cap = 0;
     if (level == 0) {
         const uint32_t B = 0xFFFF;                                     // encoder.cpp:484
         const uint32_t npk = (uint32_t)((n + B - 1) / B);
@@ -363,16 +409,18 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
         HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
         if (cks_kind != ZZ_CKS_NONE)
             hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk, B, n, cks_kind, c->d_cks_total);
+        if (chunked && chunk_sizes)                                     // WriteUncompressedBlock asks for 6 + length (encoder.cpp:488)
+            for (uint32_t k = 0; k < npk; ++k) {
+                log.push_back((uint64_t)k * (B + 5));
+                log.push_back(6 + (k + 1 < npk ? (uint64_t)B : n - (uint64_t)(npk - 1) * B));
+            }
     } else {
-        // level 1: one block for the whole input needs bitsAvailable/9 - 8 >= n (encoder.cpp:331-337); a smaller
-        // destination would make the reference cut several blocks, which this mode does not reproduce
+        // worst cases. Level 1: nine bits per byte plus ten per block; blocks of the chunked form hold at least
+        // (2^18 - 1) * 8 / 9 - 8 bytes each, and a caller-owned buffer is never overrun (the block lengths see to it).
+        // Level >= 2: every block falls back to stored blocks of <= 65535 bytes.
         const uint64_t avail = cap - hl;
-        if (level == 1 && (avail < 2 || ((avail - 1) * 8) / 9 < n + 8)) {
-            set_err("sequential level-1 stream needs a destination of at least zz_bound() bytes");
-            return ZZ_E_NOSPACE;
-        }
-        // level >= 2 worst case: every block falls back to stored blocks of <= 65535 bytes
-        const uint64_t bound = level == 1 ? ((uint64_t)9 * n + 17) / 8 + 64 : n + (n / 65535 + 2) * 5 + (n / 400000 + 2) * 8 + 64;
+        uint64_t bound = level == 1 ? ((uint64_t)9 * n + 17) / 8 + n / 65536 + 128 : n + (n / 65535 + 2) * 5 + (n / 400000 + 2) * 8 + 64;
+        if (level == 1 && !chunked && avail + 64 < bound) bound = avail + 64;
         const uint32_t P = 32768, npk_c = (uint32_t)((n + P - 1) / P);   // checksum chunks
         int rc = ensure_workspace(c, 0, npk_c, 0);
         if (rc) return rc;
@@ -381,19 +429,31 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
             HIPCHK(hipMalloc(&c->slots, bound));
             c->slots_cap = bound;
         }
+        zz_stream_ctl ctl;
+        memset(&ctl, 0, sizeof ctl);
+        ctl.cap = avail; ctl.chunked = chunked ? 1 : 0; ctl.truncated = c->d_err + 1; ctl.log_n = c->d_err + 2;
+        if (chunked) {
+            log_cap = (uint32_t)(n / 32768 + 64);                        // far more than the blocks a stream can have
+            if ((uint64_t)log_cap * 16 > c->log_cap_bytes) {
+                (void)hipFree(c->d_log); c->d_log = nullptr; c->log_cap_bytes = 0;
+                HIPCHK(hipMalloc(&c->d_log, (uint64_t)log_cap * 16));
+                c->log_cap_bytes = (uint64_t)log_cap * 16;
+            }
+            ctl.log = c->d_log; ctl.log_cap = log_cap;
+        }
         pp.packet_size = P; pp.npk = npk_c; pp.cks_kind = cks_kind; pp.cks = c->cks; pp.sizes = c->sizes;
         if (cks_kind == ZZ_CKS_CRC) hipLaunchKernelGGL(k_crc32_packets, dim3(npk_c < 2048 ? npk_c : 2048), dim3(ZZ_CRC_THREADS), 0, st, pp);
         else if (cks_kind == ZZ_CKS_ADLER) hipLaunchKernelGGL(k_adler_packets, dim3(npk_c < 4096 ? npk_c : 4096), dim3(ZZ_WAVE), 0, st, pp);
         zz_packet_params ps = pp;
-        ps.npk = 1; ps.slots = c->slots; ps.slot_stride = (uint32_t)bound; ps.cks_kind = ZZ_CKS_NONE;
+        ps.npk = 1; ps.slots = c->slots; ps.slot_stride = (uint32_t)(bound > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : bound); ps.cks_kind = ZZ_CKS_NONE;
         if (level >= 2 && (uint64_t)ZZ_ST_SCRATCH_BYTES > c->l2_scratch_cap) {
             (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
             HIPCHK(hipMalloc(&c->l2_scratch, ZZ_ST_SCRATCH_BYTES));
             c->l2_scratch_cap = ZZ_ST_SCRATCH_BYTES;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));
-        if (level == 1) hipLaunchKernelGGL(k_stream_l1, dim3(1), dim3(ZZ_WAVE), 0, st, ps);
-        else { zz_st_params q; q.pk = ps; q.scratch = c->l2_scratch; hipLaunchKernelGGL(k_stream_l2, dim3(1), dim3(ZZ_WAVE), 0, st, q); }
+        if (level == 1) hipLaunchKernelGGL(k_stream_l1, dim3(1), dim3(ZZ_WAVE), 0, st, ps, ctl);
+        else { zz_st_params q; q.pk = ps; q.scratch = c->l2_scratch; q.ctl = ctl; hipLaunchKernelGGL(k_stream_l2, dim3(1), dim3(ZZ_WAVE), 0, st, q); }
         if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
         hipLaunchKernelGGL(k_copy_stream, dim3(1024), dim3(256), 0, st, c->slots, c->sizes, d_dst + hl,
                            cap >= (uint64_t)(hl + tl) ? cap - hl - tl : 0, c->d_res);
@@ -403,12 +463,41 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, d_dst, cap, format, c->d_cks_total, n, c->d_res);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(zz_result), hipMemcpyDeviceToHost, st));
-    uint32_t kerr = 0;
-    HIPCHK(hipMemcpyAsync(&kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
+    uint32_t kerr[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpyAsync(kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *host_res = *c->h_res;
-    if (kerr) { set_err("internal: output slot overflow"); return ZZ_E_NOSPACE; }
+    if (kerr[0]) { set_err("internal: output slot overflow"); return ZZ_E_NOSPACE; }
+    if (kerr[1]) {
+        set_err("destination too small: the reference's level-1 stream stops early here (encoder.cpp:331-337,546-548)");
+        return ZZ_E_NOSPACE;
+    }
     if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    if (chunked && chunk_sizes) {
+        if (level != 0) {
+            const uint32_t nlog = kerr[2];
+            if (nlog > log_cap) { set_err("internal: chunk log overflow"); return ZZ_E_HIP; }
+            log.resize((size_t)nlog * 2);
+            if (nlog) HIPCHK(hipMemcpy(log.data(), c->d_log, (size_t)nlog * 16, hipMemcpyDeviceToHost));
+        }
+        // replay EnsureOutputLength (outputbitstream.h:171-190) over the log: a chunk starts where the rule opens one
+        zz_chunker ck = { 0, 0 };
+        std::vector<uint64_t> starts;
+        for (size_t k = 0; k + 1 < log.size(); k += 2) {
+            bool opened;
+            const int64_t room = zz_chunk_ensure(ck, log[k], (int64_t)log[k + 1], &opened);
+            if (!opened && room < (int64_t)log[k + 1]) {
+                // more than 2^18 bytes free, yet not enough for this block: the reference gives up here (encoder.cpp:
+                // 277-278) and leaves an undecodable stream; the block is in ours, so it gets a chunk of its own
+                ck.chunk_start = log[k]; ck.nchunks++; opened = true;
+            }
+            if (opened) starts.push_back(log[k]);
+        }
+        for (size_t k = 0; k < starts.size(); ++k) {
+            const uint64_t e = k + 1 < starts.size() ? starts[k + 1] : host_res->stream_bytes;
+            chunk_sizes->push_back(e - starts[k]);
+        }
+    }
     return ZZ_OK;
 }
 
@@ -419,9 +508,27 @@ extern "C" int zz_encode_stream_device(zz_ctx* c, const void* d_src, uint64_t n,
     if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
     if (format < 0 || format > 2) format = ZZ_DEFLATE;
     zz_result r;
-    int rc = encode_stream(c, (const uint8_t*)d_src, n, (uint8_t*)d_dst, cap, format, level, (hipStream_t)hip_stream, &r);
+    int rc = encode_stream(c, (const uint8_t*)d_src, n, (uint8_t*)d_dst, cap, format, level, false, nullptr, (hipStream_t)hip_stream, &r);
     if (rc) return rc;
     *out_len = r.total_bytes;
+    return ZZ_OK;
+}
+
+extern "C" int zz_encode_stream_chunks_device(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                                              int format, int level, uint64_t* chunk_sizes, uint32_t max_chunks,
+                                              uint32_t* nchunks, void* hip_stream)
+{
+    if (out_len) *out_len = ~0ull;
+    if (nchunks) *nchunks = 0;
+    if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    zz_result r;
+    std::vector<uint64_t> sizes;
+    int rc = encode_stream(c, (const uint8_t*)d_src, n, (uint8_t*)d_dst, cap, format, level, true, &sizes, (hipStream_t)hip_stream, &r);
+    if (rc) return rc;
+    *out_len = r.total_bytes;
+    if (nchunks) *nchunks = (uint32_t)sizes.size();
+    if (chunk_sizes) for (size_t k = 0; k < sizes.size() && k < max_chunks; ++k) chunk_sizes[k] = sizes[k];
     return ZZ_OK;
 }
 
@@ -506,13 +613,24 @@ extern "C" uint32_t zz_crc32(const uint8_t* p, uint64_t n, uint32_t start)
 }
 extern "C" uint32_t zz_crc32_combine(uint32_t c1, uint32_t c2, uint64_t len2) { return crc32_combine(c1, c2, len2); }
 
-// ---- default context + host-buffer entry points ------------------------------------------------------------
+// ---- host-buffer entry points: contexts, devices -----------------------------------------------------------------
+// The reference's entry points are re-entrant and, with threaded=true, fan the input out over every core of the
+// machine (zzflate.cpp:97-132). Here a call borrows one context per device it uses from a small pool (created on
+// demand, at most two per device, so concurrent callers overlap without unbounded memory) and fans the input's slabs
+// out over every visible GPU. Which devices: env ZZFLATE_DEVICES ("0,1,2" -- an index may repeat, which gives that GPU
+// several pipelines -- or "all"), else env ZZFLATE_DEVICE (one index), else all of them. No lock is held while
+// kernels run or callbacks are invoked, so a callback may call back into the library.
 static std::mutex g_mu;
-static zz_ctx* g_default = nullptr;
+static std::condition_variable g_cv;
 static uint32_t g_packet = 0;
+struct pool_entry { zz_ctx* c; bool busy; };
+static std::vector<pool_entry> g_pool;
+static std::vector<int> g_devices;
+#define ZZ_POOL_PER_DEVICE 2
 
 extern "C" uint32_t zz_get_packet_size(void)
 {
+    std::lock_guard<std::mutex> lk(g_mu);
     if (g_packet == 0) {
         const char* e = getenv("ZZFLATE_PACKET_SIZE");
         long v = e ? atol(e) : 0;
@@ -523,20 +641,80 @@ extern "C" uint32_t zz_get_packet_size(void)
 extern "C" int zz_set_packet_size(uint32_t P)
 {
     if (P == 0 || P > ZZ_MAX_PACKET_SIZE) { set_err("packet size must be 1..32768"); return ZZ_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_mu);
     g_packet = P;
     return ZZ_OK;
 }
 
-static int default_ctx(zz_ctx** out)
+// the device list of the host entry points (read once)
+static int host_devices(std::vector<int>& out)
 {
-    if (!g_default) {
-        const char* e = getenv("ZZFLATE_DEVICE");
-        int rc = zz_ctx_create(e ? atoi(e) : 0, &g_default);
-        if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_devices.empty()) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count == 0) {
+            set_err(std::string("no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(e) + ", count " +
+                    std::to_string(count) + "): this library has no CPU encode path");
+            return ZZ_E_HIP;
+        }
+        const char* list = getenv("ZZFLATE_DEVICES");
+        const char* one = getenv("ZZFLATE_DEVICE");
+        std::vector<int> v;
+        if (list && *list && strcmp(list, "all") != 0) {
+            for (const char* q = list; *q;) {
+                char* endp = nullptr;
+                const long d = strtol(q, &endp, 10);
+                if (endp == q) break;
+                if (d < 0 || d >= count) { set_err("ZZFLATE_DEVICES names a device that does not exist"); return ZZ_E_ARG; }
+                v.push_back((int)d);
+                q = *endp == ',' ? endp + 1 : endp;
+            }
+        } else if (!list && one && *one) {
+            const int d = atoi(one);
+            if (d < 0 || d >= count) { set_err("ZZFLATE_DEVICE names a device that does not exist"); return ZZ_E_ARG; }
+            v.push_back(d);
+        }
+        if (v.empty()) for (int d = 0; d < count; ++d) v.push_back(d);
+        g_devices = v;
     }
-    *out = g_default;
+    out = g_devices;
     return ZZ_OK;
 }
+// test hook (not in the public header): forget the device list so that the environment is read again
+extern "C" void zz_debug_reset_devices(void) { std::lock_guard<std::mutex> lk(g_mu); g_devices.clear(); }
+
+static int pool_acquire(int device, zz_ctx** out)
+{
+    std::unique_lock<std::mutex> lk(g_mu);
+    for (;;) {
+        int have = 0;
+        for (auto& e : g_pool)
+            if (e.c->device == device) {
+                if (!e.busy) { e.busy = true; *out = e.c; return ZZ_OK; }
+                have++;
+            }
+        if (have < ZZ_POOL_PER_DEVICE) {
+            zz_ctx* c = nullptr;
+            int rc = zz_ctx_create(device, &c);
+            if (rc) return rc;
+            g_pool.push_back({ c, true });
+            *out = c;
+            return ZZ_OK;
+        }
+        g_cv.wait(lk);
+    }
+}
+static void pool_release(zz_ctx* c)
+{
+    { std::lock_guard<std::mutex> lk(g_mu); for (auto& e : g_pool) if (e.c == c) e.busy = false; }
+    g_cv.notify_all();
+}
+struct ctx_lease {                       // contexts borrowed for one host call
+    std::vector<zz_ctx*> v;
+    ~ctx_lease() { for (zz_ctx* c : v) pool_release(c); }
+    int take(int device) { zz_ctx* c = nullptr; int rc = pool_acquire(device, &c); if (!rc) v.push_back(c); return rc; }
+};
 
 static int ensure_stage(zz_ctx* c, uint64_t in_bytes, uint64_t out_bytes)
 {
@@ -555,16 +733,16 @@ static int ensure_stage(zz_ctx* c, uint64_t in_bytes, uint64_t out_bytes)
 
 // ---- host-buffer entry points ------------------------------------------------------------------------------------
 // Where the compressed bytes go: straight into the caller's destination (ZzFlateEncode, zzflate.cpp:225-242) or
-// through the callback in library-owned chunks of at most 1,000,000 bytes (ZzFlateEncodeToCallback, zzflate.cpp:
-// 197-222, outputbitstream.h:183): header and trailer are calls of their own, as in the reference.
+// through the callback in library-owned chunks (ZzFlateEncodeToCallback, zzflate.cpp:197-222): at most 1,000,000 bytes
+// each (outputbitstream.h:183); header and trailer are calls of their own, as in the reference.
 struct host_sink {
     // destination form
     uint8_t* dest = nullptr; uint64_t cap = 0, pos = 0; bool overflow = false;
     // callback form
     zz_callback cb = nullptr; void* user = nullptr; std::vector<uint8_t> chunk;
-    void raw(const uint8_t* p, uint64_t n)            // header / trailer
+    void raw(const uint8_t* p, uint64_t n)            // header / trailer / a chunk with the reference's own boundaries
     {
-        if (cb) { flush(); cb(user, p, n); return; }
+        if (cb) { flush(); if (n) cb(user, p, n); return; }
         put(p, n);
     }
     void put(const uint8_t* p, uint64_t n)            // stream bytes
@@ -610,6 +788,10 @@ static uint64_t slab_bytes(uint32_t P)
     return s < P ? P : s / P * P;          // slabs are cut at packet boundaries
 }
 
+// bytes of input kept in front of a slab on the device: level >= 2 extends matches backward over at most 258 bytes
+// (encoder.cpp:92-102,404, capped as D11 says) and compares eight at a time
+#define ZZ_SLAB_HALO 4096ull
+
 static int ensure_pipe(zz_ctx* c, uint64_t slab, uint64_t slab_bound)
 {
     if (!c->s_in) {
@@ -621,11 +803,15 @@ static int ensure_pipe(zz_ctx* c, uint64_t slab, uint64_t slab_bound)
             HIPCHK(hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
         }
     }
-    if (slab > c->pin_in_cap) {
-        for (int i = 0; i < 2; ++i) { (void)hipHostFree(c->pin_in[i]); c->pin_in[i] = nullptr; }
+    const uint64_t in_bytes = ZZ_SLAB_HALO + slab;
+    if (in_bytes > c->pin_in_cap) {
+        for (int i = 0; i < 2; ++i) { (void)hipHostFree(c->pin_in[i]); c->pin_in[i] = nullptr; (void)hipFree(c->slab_in[i]); c->slab_in[i] = nullptr; }
         c->pin_in_cap = 0;
-        for (int i = 0; i < 2; ++i) HIPCHK(hipHostMalloc((void**)&c->pin_in[i], slab, hipHostMallocDefault));
-        c->pin_in_cap = slab;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipHostMalloc((void**)&c->pin_in[i], in_bytes, hipHostMallocDefault));
+            HIPCHK(hipMalloc(&c->slab_in[i], in_bytes + 64));
+        }
+        c->pin_in_cap = in_bytes;
     }
     if (slab_bound > c->pin_out_cap) {
         for (int i = 0; i < 2; ++i) { (void)hipHostFree(c->pin_out[i]); c->pin_out[i] = nullptr; (void)hipFree(c->slab_out[i]); c->slab_out[i] = nullptr; }
@@ -639,75 +825,124 @@ static int ensure_pipe(zz_ctx* c, uint64_t slab, uint64_t slab_bound)
     return ZZ_OK;
 }
 
-// Packet mode on a host buffer, SURVEY.md 8(f).1: the input crosses PCIe in slabs of whole packets while earlier
-// slabs are encoded (as shards of one stream: no container, checksum partials combined here) and their output
-// travels back. Three streams, two pinned buffers per direction; the device keeps the whole input (level >= 2
-// looks up to 258 bytes behind a slab's first byte).
-static int encode_host_pipelined(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, uint32_t P, host_sink& sink)
+// Packet mode on a host buffer (SURVEY.md 8f.1 and the device analogue of the std::async fan-out, zzflate.cpp:97-155).
+// The input is cut into slabs of whole packets; slab i belongs to device i mod D. Every device runs its own pipeline
+// on its own host thread: the slab crosses PCIe (through a pinned buffer) while the device's previous slab is encoded
+// as a shard of the stream (no container; checksum partial returned) and the one before that travels back. Only two
+// slabs of input -- each with the 4 KiB in front of it, for level >= 2's backward match extension -- and two of output
+// live on a device at any time, so the input may be far larger than HBM. The calling thread is the in-order join: it
+// hands the slabs' bytes to the sink as they arrive and folds the checksum partials (adler.cpp:5-15 / GF(2) shifts).
+static int encode_host_slabs(const std::vector<zz_ctx*>& ctxs, const uint8_t* src, uint64_t n, int format, int level, uint32_t P,
+                             host_sink& sink)
 {
     const uint64_t slab = slab_bytes(P);
     const uint64_t nslab = (n + slab - 1) / slab;
     const uint64_t sb = zz_bound(slab, ZZ_DEFLATE, level, P);
-    int rc = ensure_stage(c, n, 0);
-    if (rc) return rc;
-    rc = ensure_pipe(c, slab, sb);
-    if (rc) return rc;
+    const int D = (int)ctxs.size();
     const int ck = format == ZZ_ZLIB ? ZZ_ZLIB : format == ZZ_GZIP ? ZZ_GZIP : ZZ_DEFLATE;
-    uint8_t hdr[10], trl[8];
-    sink.raw(hdr, (uint64_t)zz_header(format, hdr));
-    uint32_t acc = format == ZZ_ZLIB ? 1u : 0u;          // running checksum of everything in front of the slab
+
+    std::mutex mu;
+    std::condition_variable cv;
     std::vector<uint64_t> out_len(nslab, 0);
-    auto stage_in = [&](uint64_t i) -> int {
-        const uint64_t off = i * slab, len = n - off < slab ? n - off : slab;
-        const int b = (int)(i & 1);
-        if (i >= 2) HIPCHK(hipEventSynchronize(c->ev_in[b]));                 // the slab that used this buffer has left it
-        host_sink::memcpy_mt(c->pin_in[b], src + off, len);
-        HIPCHK(hipMemcpyAsync(c->stage_in + off, c->pin_in[b], len, hipMemcpyHostToDevice, c->s_in));
-        HIPCHK(hipEventRecord(c->ev_in[b], c->s_in));
-        return ZZ_OK;
+    std::vector<uint32_t> part(nslab, 0);
+    std::vector<uint8_t> ready(nslab, 0), consumed(nslab, 0);
+    int err = 0;
+    std::string errmsg;
+    auto fail = [&](int rc) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!err) { err = rc; errmsg = g_err; }
+        cv.notify_all();
     };
-    auto deliver = [&](uint64_t i) -> int {
-        const int b = (int)(i & 1);
-        HIPCHK(hipEventSynchronize(c->ev_out[b]));
-        sink.put(c->pin_out[b], out_len[i]);
-        return ZZ_OK;
+
+    auto worker = [&](int d) {
+        zz_ctx* c = ctxs[d];
+        auto run = [&]() -> int {
+            HIPCHK(hipSetDevice(c->device));
+            int rc = ensure_pipe(c, slab, sb);
+            if (rc) return rc;
+            auto stage_in = [&](uint64_t j) -> int {                       // j: this device's j-th slab
+                const uint64_t i = (uint64_t)d + j * D, off = i * slab, len = n - off < slab ? n - off : slab;
+                const uint64_t h = off < ZZ_SLAB_HALO ? off : ZZ_SLAB_HALO;
+                const int b = (int)(j & 1);
+                // pin_in[b] / slab_in[b] were last used by slab j-2, whose encode has returned
+                host_sink::memcpy_mt(c->pin_in[b] + ZZ_SLAB_HALO - h, src + off - h, h + len);
+                HIPCHK(hipMemcpyAsync(c->slab_in[b] + ZZ_SLAB_HALO - h, c->pin_in[b] + ZZ_SLAB_HALO - h, h + len, hipMemcpyHostToDevice, c->s_in));
+                HIPCHK(hipEventRecord(c->ev_in[b], c->s_in));
+                return ZZ_OK;
+            };
+            const uint64_t mine = nslab > (uint64_t)d ? (nslab - d + D - 1) / D : 0;
+            if (mine == 0) return ZZ_OK;
+            rc = stage_in(0);
+            if (rc) return rc;
+            for (uint64_t j = 0; j < mine; ++j) {
+                const uint64_t i = (uint64_t)d + j * D, off = i * slab, len = n - off < slab ? n - off : slab;
+                const uint64_t h = off < ZZ_SLAB_HALO ? off : ZZ_SLAB_HALO;
+                const int b = (int)(j & 1);
+                if (j + 1 < mine) { rc = stage_in(j + 1); if (rc) return rc; }     // the next slab's copy runs under this slab's encode
+                HIPCHK(hipStreamWaitEvent(c->s_enc, c->ev_in[b], 0));
+                if (j >= 2) {
+                    // the output buffers of slab j-2: its copy back must be over, and the join must have taken the bytes
+                    HIPCHK(hipStreamWaitEvent(c->s_enc, c->ev_out[b], 0));
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return err || consumed[i - 2 * (uint64_t)D]; });
+                    if (err) return ZZ_OK;
+                }
+                uint64_t w = 0; uint32_t pc = 0;
+                rc = zz_encode_shard_device(c, c->slab_in[b] + ZZ_SLAB_HALO, len, h, i + 1 == nslab, c->slab_out[b], c->slab_out_cap, &w, &pc,
+                                            ck, level, P, (void*)c->s_enc);     // returns when the slab is encoded
+                if (rc) return rc;
+                HIPCHK(hipMemcpyAsync(c->pin_out[b], c->slab_out[b], w, hipMemcpyDeviceToHost, c->s_out));
+                HIPCHK(hipEventRecord(c->ev_out[b], c->s_out));              // the join waits for it; this thread moves on
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    out_len[i] = w; part[i] = pc; ready[i] = 1;
+                }
+                cv.notify_all();
+                { std::lock_guard<std::mutex> lk(mu); if (err) return ZZ_OK; }
+            }
+            return ZZ_OK;
+        };
+        const int rc = run();
+        if (rc) fail(rc);
     };
-    rc = stage_in(0);
-    if (rc) return rc;
+
+    std::vector<std::thread> threads;
+    for (int d = 0; d < D; ++d) threads.emplace_back(worker, d);
+    uint8_t hdr[10], trl[8];
+    uint32_t acc = format == ZZ_ZLIB ? 1u : 0u;          // running checksum of everything in front of the slab
     for (uint64_t i = 0; i < nslab; ++i) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return err || ready[i]; });
+            if (err) break;
+        }
+        if (i == 0) sink.raw(hdr, (uint64_t)zz_header(format, hdr));    // nothing is delivered before a slab has encoded
         const uint64_t off = i * slab, len = n - off < slab ? n - off : slab;
-        const int b = (int)(i & 1);
-        if (i + 1 < nslab) { rc = stage_in(i + 1); if (rc) return rc; }       // next slab's copy runs under this slab's encode
-        HIPCHK(hipStreamWaitEvent(c->s_enc, c->ev_in[b], 0));
-        if (i >= 2) HIPCHK(hipStreamWaitEvent(c->s_enc, c->ev_out[b], 0));    // the output slab is free again
-        uint64_t w = 0; uint32_t part = 0;
-        rc = zz_encode_shard_device(c, c->stage_in + off, len, off, i + 1 == nslab, c->slab_out[b], c->slab_out_cap, &w, &part,
-                                    ck, level, P, (void*)c->s_enc);     // returns when the slab is encoded
-        if (rc) return rc;
-        out_len[i] = w;
-        acc = format == ZZ_ZLIB ? adler_combine(acc, part, len) : format == ZZ_GZIP ? crc32_combine(acc, part, len) : 0u;
-        HIPCHK(hipMemcpyAsync(c->pin_out[b], c->slab_out[b], w, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipEventRecord(c->ev_out[b], c->s_out));
-        if (i >= 1) { rc = deliver(i - 1); if (rc) return rc; }
+        zz_ctx* c = ctxs[i % D];
+        const int b = (int)((i / D) & 1);
+        if (hipEventSynchronize(c->ev_out[b]) != hipSuccess) { set_err("hipEventSynchronize failed in the slab join"); fail(ZZ_E_HIP); break; }
+        sink.put(c->pin_out[b], out_len[i]);
+        acc = format == ZZ_ZLIB ? adler_combine(acc, part[i], len) : format == ZZ_GZIP ? crc32_combine(acc, part[i], len) : 0u;
+        { std::lock_guard<std::mutex> lk(mu); consumed[i] = 1; }
+        cv.notify_all();
     }
-    rc = deliver(nslab - 1);
-    if (rc) return rc;
+    for (auto& t : threads) t.join();
+    if (err) { set_err(errmsg); return err; }
     sink.raw(trl, (uint64_t)zz_trailer(format, acc, n, trl));
     sink.flush();
     return ZZ_OK;
 }
 
-// everything else (one slab or less, or the sequential whole-buffer stream): one copy in, one call, one copy out
-static int encode_host_simple(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, uint32_t P, bool sequential,
-                              host_sink& sink)
+// one slab or less: one copy in, one call, one copy out
+static int encode_host_simple(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, uint32_t P, host_sink& sink)
 {
     const uint64_t bound = zz_bound(n, format, level, P);
+    HIPCHK(hipSetDevice(c->device));
     int rc = ensure_stage(c, n, bound);
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpy(c->stage_in, src, n, hipMemcpyHostToDevice));
     uint64_t total = 0;
-    rc = sequential ? zz_encode_stream_device(c, c->stage_in, n, c->stage_out, bound, &total, format, level, nullptr)
-                    : zz_encode_device(c, c->stage_in, n, c->stage_out, bound, &total, format, level, P, nullptr);
+    rc = zz_encode_device(c, c->stage_in, n, c->stage_out, bound, &total, format, level, P, nullptr);
     if (rc) return rc;
     std::vector<uint8_t> host(total);
     if (total) HIPCHK(hipMemcpy(host.data(), c->stage_out, total, hipMemcpyDeviceToHost));
@@ -719,21 +954,67 @@ static int encode_host_simple(zz_ctx* c, const uint8_t* src, uint64_t n, int for
     return ZZ_OK;
 }
 
+// threaded == false: the reference's single Encoder over the whole input (zzflate.cpp:84-95). Its output depends on
+// where it goes: into the caller's buffer the level-1 block lengths follow from the buffer's size; through the callback
+// they follow from the library's own 1,000,000-byte chunks, and the callback sees exactly those chunks.
+static int encode_host_sequential(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, host_sink& sink)
+{
+    const bool chunked = sink.cb != nullptr;
+    const uint64_t hl = header_len(format), tl = trailer_len(format);
+    // device buffer for the stream: level 1 never needs more than nine bits per byte plus ten per block
+    uint64_t bound = zz_bound(n, format, level, ZZ_DEFAULT_PACKET) + n / 65536 + 256;
+    uint64_t cap = bound;
+    if (!chunked && level == 1 && sink.cap < cap) cap = sink.cap;      // the caller's capacity decides the block lengths
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_stage(c, n, cap > bound ? cap : bound);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpy(c->stage_in, src, n, hipMemcpyHostToDevice));
+    zz_result r;
+    std::vector<uint64_t> chunks;
+    rc = encode_stream(c, c->stage_in, n, c->stage_out, cap, format, level, chunked, chunked ? &chunks : nullptr, nullptr, &r);
+    if (rc) return rc;
+    const uint64_t total = r.total_bytes;
+    std::vector<uint8_t> host(total);
+    if (total) HIPCHK(hipMemcpy(host.data(), c->stage_out, total, hipMemcpyDeviceToHost));
+    sink.raw(host.data(), hl);
+    if (chunked) {
+        uint64_t o = hl;
+        for (uint64_t k : chunks) { sink.raw(host.data() + o, k); o += k; }   // one call per chunk (zzflate.cpp:207-215)
+    } else {
+        sink.put(host.data() + hl, total - hl - tl);
+    }
+    sink.raw(host.data() + total - tl, tl);
+    sink.flush();
+    return ZZ_OK;
+}
+
 static int encode_host(const uint8_t* src, uint64_t n, const zz_config* cfg, host_sink& sink)
 {
     const int level = cfg->level;
     if (level < 0 || level > 3) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
-    std::lock_guard<std::mutex> lk(g_mu);
-    zz_ctx* c;
-    int rc = default_ctx(&c);
+    if (!src && n) { set_err("null source"); return ZZ_E_ARG; }
+    std::vector<int> devs;
+    int rc = host_devices(devs);
     if (rc) return rc;
     const uint32_t P = zz_get_packet_size();
     int format = cfg->format;
     if (format < 0 || format > 2) format = ZZ_DEFLATE;
-    HIPCHK(hipSetDevice(c->device));
-    const bool sequential = !cfg->threaded && n > P;   // more than one packet: the reference's whole-buffer stream
-    if (!sequential && n > slab_bytes(P)) return encode_host_pipelined(c, src, n, format, level, P, sink);
-    return encode_host_simple(c, src, n, format, level, P, sequential, sink);
+    ctx_lease lease;
+    if (!cfg->threaded && n > 0) {
+        rc = lease.take(devs[0]);
+        if (rc) return rc;
+        return encode_host_sequential(lease.v[0], src, n, format, level, sink);
+    }
+    const uint64_t slab = slab_bytes(P);
+    const uint64_t nslab = (n + slab - 1) / slab;
+    if (nslab <= 1) {
+        rc = lease.take(devs[0]);
+        if (rc) return rc;
+        return encode_host_simple(lease.v[0], src, n, format, level, P, sink);
+    }
+    const size_t D = devs.size() < nslab ? devs.size() : (size_t)nslab;
+    for (size_t d = 0; d < D; ++d) { rc = lease.take(devs[d]); if (rc) return rc; }
+    return encode_host_slabs(lease.v, src, n, format, level, P, sink);
 }
 
 extern "C" int zz_encode(uint8_t* dest, uint64_t* dest_len, const uint8_t* src, uint64_t n, const zz_config* cfg)
@@ -759,6 +1040,15 @@ extern "C" int zz_encode_callback(const uint8_t* src, uint64_t n, const zz_confi
     sink.cb = cb; sink.user = user;
     sink.chunk.reserve(1000000);
     return encode_host(src, n, cfg, sink);
+}
+
+// diagnostic (not in the public header): device bytes the host entry points' contexts hold for input/output staging
+extern "C" uint64_t zz_debug_host_staging_bytes(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint64_t t = 0;
+    for (auto& e : g_pool) t += e.c->stage_in_cap + e.c->stage_out_cap + 2 * (e.c->pin_in_cap ? e.c->pin_in_cap + 64 : 0) + 2 * (e.c->slab_out_cap ? e.c->slab_out_cap + 64 : 0);
+    return t;
 }
 
 // ---- synthetic inputs -----------------------------------------------------------------------------------------

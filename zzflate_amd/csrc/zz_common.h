@@ -37,6 +37,44 @@ struct zz_packet_params {
     unsigned long long* prof; // diagnostic builds (-DZZ_PROF) only: per-phase cycle sums; ignored otherwise
 };
 
+// ---- the sequential stream's output buffers (outputbitstream.h:171-201) ------------------------------------------
+// A single Encoder asks EnsureOutputLength(length) at every block start. With a caller-owned buffer the answer is the
+// room left in it; through the callback API the library owns chunks of 1,000,000 bytes and opens a new one when the
+// current one is not "enough" (more than twice the length asked for, or more than 2^18 bytes). Block sizes at level 1
+// follow from that answer (encoder.cpp:331-337), and the chunks are what the callback receives (zzflate.cpp:207-215),
+// so the rule is shared by the stream kernels (which apply it) and the host (which replays the kernels' log of
+// (bytes stored, length asked for) pairs to find the chunk boundaries).
+#define ZZ_CHUNK_BYTES 1000000ll
+struct zz_chunker {
+    uint64_t chunk_start;     // bytes stored when the current chunk was opened
+    uint32_t nchunks;         // chunks opened so far
+};
+// returns AvailableBytes() after the call; *opened = a new chunk starts at `stored`
+__host__ __device__ inline int64_t zz_chunk_ensure(zz_chunker& k, uint64_t stored, int64_t length, bool* opened)
+{
+    const int64_t avail = k.nchunks ? (int64_t)(k.chunk_start + ZZ_CHUNK_BYTES) - (int64_t)stored : 0;
+    *opened = false;
+    if (avail > 2 * length || avail > (1 << 18)) return avail;          // IsEnough, outputbitstream.h:192-201
+    k.chunk_start = stored;
+    k.nchunks++;
+    *opened = true;
+    return ZZ_CHUNK_BYTES;
+}
+// what the stream kernels get besides zz_packet_params
+struct zz_stream_ctl {
+    uint64_t cap;             // fixed form: bytes of the caller's buffer behind the container header (encoder sees dest+hl)
+    int chunked;              // 0: caller-owned buffer of `cap` bytes, 1: library-owned chunks (callback API)
+    uint64_t* log;            // chunked: (bytes stored, length asked for) per EnsureOutputLength call, or null
+    uint32_t log_cap;         // pairs that fit
+    uint32_t* log_n;          // pairs written (may exceed log_cap: the host then reports an error)
+    uint32_t* truncated;      // set when the reference would have stopped early (no room left): the stream is incomplete
+};
+__device__ __forceinline__ void zz_log_ensure(const zz_stream_ctl& C, uint32_t& nlog, uint64_t stored, uint64_t need)
+{
+    if ((threadIdx.x & 63) == 0 && C.log && nlog < C.log_cap) { C.log[2 * nlog] = stored; C.log[2 * nlog + 1] = need; }
+    nlog++;
+}
+
 #ifdef ZZ_PROF
 #define ZZ_PROF_DECL unsigned long long prof_acc[16] = {0}; unsigned long long prof_last; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last) :: "memory");
 // stamp form of cdna_hip_programming.md section 7: one asm statement, fenced against the scheduler

@@ -20,11 +20,13 @@
 //   5. tokens are turned into fixed-Huffman fragments and appended through the bit ring (zz_emit.h) -- one
 //      iteration later, in the shadow of the next group's candidate loads (software pipelining).
 //
-// Measured on MI355X (rocprofv3 SQ counters, profiles/): a wave retires about one instruction per 4 cycles and
-// only ~9 waves fit a CU (the 16 KiB table), so the loop is bound by its dynamic instruction count and by
-// dependent LDS/memory round trips, not by bandwidth. Hence: no s_barrier (one wave per workgroup, LDS ops
-// execute in order), candidate loads issued before the dup scan, a branch-light fast path in the walk, and
-// bounds-checked loads only in the last two packets of a shard.
+// Measured on MI355X (rocprofv3 SQ counters, profiles/): a parsing wave retires about one instruction per 8 cycles
+// and only ~9 packets fit a CU (the 16 KiB table), so the loop is bound by the parser's dynamic instruction count and
+// by dependent LDS/memory round trips, not by bandwidth. Hence: a second wavefront per workgroup takes everything that
+// is not on the parse's dependency chain (Adler-32, Huffman coding, bit packing; one s_barrier per group of 64
+// positions hands the tokens over), no barrier inside a wave (LDS ops of one wave execute in order), candidate loads
+// issued before the same-hash scan, a branch-light hand-written fast path in the walk, and bounds-checked loads only
+// where a 16-byte load could leave the shard.
 #pragma once
 #include "zz_checksum.h"
 #include "zz_emit.h"
@@ -213,17 +215,19 @@ __device__ __forceinline__ void l1_group_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 template <bool SAFE, typename TT, bool SPLIT = false>
+// The block is src[start, n): positions are offsets from `src` (table entries carry over from earlier blocks of the
+// same stream, encoder.cpp:320-327,370), match lengths stop at n.
 __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T, const uint32_t* lcodes,
                                                bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n,
-                                               uint32_t* tokbuf = nullptr)
+                                               uint32_t* tokbuf = nullptr, uint32_t start = 0)
 {
     const int lane = lane_id();
     ZZ_PROF_DECL
     uint32_t grp = 0;
-    uint32_t cur = 0;
+    uint32_t cur = start;
     uint32_t ptok = 0;                                                    // previous group's tokens
     uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position
-    if ((uint32_t)lane < n) ld128<SAFE>(src + lane, end, w, w2);
+    if (start + (uint32_t)lane < n) ld128<SAFE>(src + start + lane, end, w, w2);
     while (cur < n) {
         const uint32_t nact = (n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE;
         const uint64_t actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1);
@@ -242,14 +246,14 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         const uint32_t old = (sizeof(TT) == 4 && p + 1 - oldraw > 0x8000u) ? 0 : oldraw;
         uint64_t wc = 0, wc2 = 0;
         if (active && old) ld128<SAFE>(src + (old - 1), end, wc, wc2);  // encoder.cpp:350
-        if (SPLIT && cur) l1_group_barrier();                           // second half of the previous group's hand-over
+        if (SPLIT && cur != start) l1_group_barrier();                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
         if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
 
         ZZ_T(1);
         // (1a) the previous group's tokens leave while those loads are in flight
-        if (!SPLIT && cur) l1_emit_tokens(ring, lcodes, ptok);
+        if (!SPLIT && cur != start) l1_emit_tokens(ring, lcodes, ptok);
 
         ZZ_T(2);
         // (1b) which lanes share a hash inside the group?
@@ -477,8 +481,9 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
         bitring none;
         none.ring = nullptr; none.out32 = nullptr; none.bitpos = 0; none.flushed = 0;
         if (n > 0) {
-            // loads may run up to 8 bytes past the packet: only the last two packets can leave the buffer that way
-            if (k + 2 >= P.npk) l1_encode_body<true, uint16_t, true>(P, T, nullptr, none, src, end, n, tokbuf);
+            // 16-byte loads may run up to 15 bytes past the packet's last byte: bounds-checked loads wherever that
+            // would leave the shard (decided by bytes, not by packet index: packets may be as short as one byte)
+            if (off + len + 16 > P.n) l1_encode_body<true, uint16_t, true>(P, T, nullptr, none, src, end, n, tokbuf);
             else l1_encode_body<false, uint16_t, true>(P, T, nullptr, none, src, end, n, tokbuf);
         }
         return;
@@ -517,16 +522,20 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
 }
 
 // The sequential whole-buffer stream of the reference (threaded=false: zzflate.cpp:84-95, one Encoder over the
-// whole input). With a destination of at least zz_bound() bytes level 1 emits ONE fixed-Huffman block for the whole
-// input (encoder.cpp:331-337), which is inherently serial: one wavefront, 32-bit table entries. A compatibility
-// mode, not a throughput mode (use threaded=true for that). Output goes to slot 0; *stream_bytes gets its length.
-__global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P)
+// whole input) at level 1: AddData (encoder.cpp:539-552) calls WriteBlockFixedHuff until the input is used up, and every
+// call encodes as many bytes as are certain to fit the output buffer at nine bits each (encoder.cpp:331-337). With a
+// roomy caller-owned buffer that is ONE block for the whole input; with a tight one (zztest/Test.cpp:206-212,255-258
+// pass dest = input size) or the callback API's 1,000,000-byte chunks it is a chain of blocks whose lengths depend on
+// how well the earlier ones compressed. The hash table carries over (FixHashTable, encoder.cpp:320-327,370: positions
+// here are offsets from the stream's first byte, so nothing needs rebasing), matches stop at the block end. Inherently
+// serial: one wavefront, 32-bit table entries. A compatibility mode, not a throughput mode (threaded=true is that).
+// Output goes to slot 0; sizes[0] gets its length (< 4 GiB: the host admits inputs below 2 GiB, as the reference's int lengths do).
+__global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P, zz_stream_ctl C)
 {
     __shared__ uint32_t T[ZZ_HASH_SIZE];          // absolute position + 1, 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
     __shared__ uint32_t lcodes[ZZ_MAX_LEN - 2];
     const int lane = lane_id();
-    const uint32_t n = (uint32_t)P.n;
     {
         uint4* t4 = (uint4*)T;
         for (int i = lane; i < (int)(sizeof(T) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
@@ -535,13 +544,47 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P)
     bitring ring;
     ring_init(ring, ring_words, P.slots);
     uint32_t* const out0 = ring.out32;
-    ring_append_uniform(ring, 1u | (1u << 1), 3);                      // StartBlock(FixedHuffman, final)
-    if (n) l1_encode_body<true, uint32_t>(P, T, lcodes, ring, P.src, P.src + P.n, n);
-    ring_append_uniform(ring, 0, 7);                                   // codes_f[256]
+    zz_chunker ck = { 0, 0 };
+    uint32_t nlog = 0;
+    uint64_t done = 0;                                                  // input bytes encoded so far
+    bool truncated = false;
+    while (done < P.n) {                                                // AddData, encoder.cpp:539-552
+        const int64_t byteCount = (int64_t)(P.n - done);
+        // EnsureOutputLength(byteCount) - 1 (encoder.cpp:331): the packer stores whole 64-bit words
+        // (outputbitstream.h:83-98), so "bytes stored" is the bit count rounded down to 64
+        const uint64_t bits = (uint64_t)(ring.out32 - out0) * 32 + ring.bitpos;
+        const uint64_t stored = (bits >> 6) << 3;
+        int64_t avail;
+        if (C.chunked) {
+            bool opened;
+            avail = zz_chunk_ensure(ck, stored, byteCount, &opened);
+            zz_log_ensure(C, nlog, stored, (uint64_t)byteCount);
+        } else {
+            avail = (int64_t)C.cap - (int64_t)stored;
+        }
+        avail -= 1;
+        int64_t nb = (avail * 8) / 9 - 8;                               // encoder.cpp:332-333
+        bool final = true;
+        if (nb < byteCount) final = false;                              // encoder.cpp:334-337
+        else nb = byteCount;
+        ring_append_uniform(ring, (final ? 1u : 0u) | (1u << 1), 3);    // StartBlock(FixedHuffman, final)
+        if (nb <= 0) {
+            // no room for even one byte: the reference writes this empty block and AddData gives up (encoder.cpp:546-
+            // 548), leaving a stream that does not decode. Reported to the caller.
+            ring_append_uniform(ring, 0, 7);
+            truncated = true;
+            break;
+        }
+        l1_encode_body<true, uint32_t>(P, T, lcodes, ring, P.src, P.src + P.n, (uint32_t)(done + (uint64_t)nb), nullptr, (uint32_t)done);
+        ring_append_uniform(ring, 0, 7);                                // codes_f[256], encoder.cpp:371
+        done += (uint64_t)nb;
+    }
     const uint64_t bytes = (uint64_t)(ring.out32 - out0) * 4 + ring_finish(ring);
     if (lane == 0) {
-        P.sizes[0] = (uint32_t)bytes;                                  // < 4 GiB by the host's size check
+        P.sizes[0] = (uint32_t)bytes;
         if (bytes > (uint64_t)P.slot_stride * P.npk) atomicOr(P.err, 1u);
+        if (C.log_n) *C.log_n = nlog;
+        if (truncated && C.truncated) *C.truncated = 1u;
     }
 }
 

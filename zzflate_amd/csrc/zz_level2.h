@@ -1001,8 +1001,9 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
             if (wave == 0) {
-                // loads may run a few bytes past the packet: only the last two packets can leave the buffer that way
-                if (k + 2 >= P.npk) l2_token_pass<true>(T, hb, src, end, n, before, P.prof);
+                // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
+                // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
+                if (off + len + 16 > P.n) l2_token_pass<true>(T, hb, src, end, n, before, P.prof);
                 else l2_token_pass<false>(T, hb, src, end, n, before, P.prof);
             } else {
                 uint32_t nb = 0, adA = 0;

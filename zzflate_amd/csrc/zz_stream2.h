@@ -218,6 +218,7 @@ __device__ __forceinline__ void st_stored_block(bitring& ring, const uint8_t* p,
 struct zz_st_params {
     zz_packet_params pk;      // src, n, slots (one big output slot), sizes[0], err
     uint8_t* scratch;         // ZZ_ST_SCRATCH_BYTES
+    zz_stream_ctl ctl;        // callback form: log of the EnsureOutputLength calls (the host cuts the chunks from it)
 };
 
 __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
@@ -257,6 +258,14 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
     ring_init(ring, ring_words, P.slots);
     uint32_t* const out0 = ring.out32;
 
+    // "bytes stored" as EnsureOutputLength sees them (outputbitstream.h:167-176): exact at the last Flush (the end of a
+    // stored block, outputbitstream.h:155-160), whole 64-bit words of the packer since then
+    uint64_t flush_bits = 0;
+    uint32_t nlog = 0;
+    auto stored_now = [&]() -> uint64_t {
+        const uint64_t bits = (uint64_t)(ring.out32 - out0) * 32 + ring.bitpos;
+        return (flush_bits >> 3) + (((bits - flush_bits) >> 6) << 3);
+    };
     uint64_t pos = 0;                                                    // AddData loop (encoder.cpp:539-552)
     while (pos < P.n) {
         const uint64_t remaining = P.n - pos;
@@ -338,7 +347,9 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
             uint32_t written = 0;
             while (written < length) {
                 const uint32_t c = length - written < 0xFFFF ? length - written : 0xFFFF;
+                zz_log_ensure(Q.ctl, nlog, stored_now(), 6 + (uint64_t)c);          // encoder.cpp:488
                 st_stored_block(ring, src + written, c, final && c == length - written);
+                flush_bits = (uint64_t)(ring.out32 - out0) * 32 + ring.bitpos;       // WriteBytes flushed the packer
                 written += c;
             }
         } else {
@@ -348,6 +359,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
                 generate_codes(metaLens, 19, metaCodes, misc + 16);
             }
             __syncthreads();
+            zz_log_ensure(Q.ctl, nlog, stored_now(), required);                      // encoder.cpp:276
             const bool bfinal = length < byteCount ? false : final;     // :280
             ring_append_uniform(ring, (bfinal ? 1u : 0u) | (2u << 1) | (29u << 3) | (29u << 8) | (15u << 13), 17);
             {
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
     if (lane == 0) {
         P.sizes[0] = (uint32_t)bytes;
         if (bytes > (uint64_t)P.slot_stride) atomicOr(P.err, 1u);
+        if (Q.ctl.log_n) *Q.ctl.log_n = nlog;
     }
 }
 

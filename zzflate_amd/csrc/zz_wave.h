@@ -5,10 +5,11 @@
 
 namespace zz {
 
-// The encode kernels run ONE wavefront per workgroup. LDS instructions of one wave execute in issue order,
-// so cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt -- only the compiler must keep the
-// program order of the LDS accesses. A wavefront-scope fence does exactly that and emits no instruction
-// (in particular it does not drain outstanding global loads the way __syncthreads() does).
+// Inside ONE wavefront, LDS instructions execute in issue order, so lane-to-lane hand-offs through LDS need no
+// s_barrier and no s_waitcnt -- only the compiler must keep the program order of the LDS accesses. A wavefront-scope
+// fence does exactly that and emits no instruction (in particular it does not drain outstanding global loads the way
+// __syncthreads() does). The encode kernels run two wavefronts per workgroup (parser + emitter/helper); those two meet
+// at explicit s_barriers (l1_group_barrier, l2_block_barrier), never through this macro.
 #define ZZ_WAVE_SYNC()                                              \
     do {                                                            \
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      \
