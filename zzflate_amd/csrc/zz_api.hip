@@ -486,9 +486,10 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
         for (size_t k = 0; k + 1 < log.size(); k += 2) {
             bool opened;
             const int64_t room = zz_chunk_ensure(ck, log[k], (int64_t)log[k + 1], &opened);
-            if (!opened && room < (int64_t)log[k + 1]) {
-                // more than 2^18 bytes free, yet not enough for this block: the reference gives up here (encoder.cpp:
-                // 277-278) and leaves an undecodable stream; the block is in ours, so it gets a chunk of its own
+            if (level >= 2 && !opened && room < (int64_t)log[k + 1]) {
+                // a dynamic block that needs more than the > 2^18 bytes still free: the reference gives up here
+                // (encoder.cpp:277-278) and leaves an undecodable stream; the block is in ours, so it gets a chunk of
+                // its own. (At level 1 the length asked for is only a wish: the block is cut to what fits.)
                 ck.chunk_start = log[k]; ck.nchunks++; opened = true;
             }
             if (opened) starts.push_back(log[k]);
