@@ -55,6 +55,7 @@ def _load():
     except ImportError:
         pass
     path = _build.build()          # returns at once when the library is newer than every source under csrc/ and include/
+    path = os.environ.get("ZZFLATE_AMD_LIB", path)      # diagnostics: an experimental build of the same sources
     L = ctypes.CDLL(path)
     u64, u32, i32, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
     pu64 = ctypes.POINTER(ctypes.c_uint64)

@@ -66,6 +66,10 @@ struct zz_ctx {
     zz_verify_params last = {};  bool have_last = false;
     unsigned long long* d_verify = nullptr;
     uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
+    // level 1: the second kernel (hash tables in global memory) runs beside the first on its own stream
+    uint16_t* d_gtables = nullptr; uint32_t* d_gfree = nullptr;
+    hipStream_t s_aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int num_cus = 0;
     uint64_t* d_log = nullptr; uint64_t log_cap_bytes = 0;   // sequential stream, callback form: EnsureOutputLength log
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -122,6 +126,10 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
+        HIPCHK(hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        HIPCHK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         return ZZ_OK;
     }();
     if (rc) { zz_ctx_destroy(c); return rc; }                            // nothing allocated so far is left behind
@@ -146,6 +154,10 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     if (c->s_enc) (void)hipStreamDestroy(c->s_enc);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     (void)hipHostFree(c->h_res);
+    (void)hipFree(c->d_gtables); (void)hipFree(c->d_gfree);
+    if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -161,6 +173,7 @@ extern "C" int zz_debug_occupancy(int level)
 {
     int nb = -1;
     if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
+    else if (level == 11) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1g, ZZ_L1_THREADS, 0);
     else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
@@ -208,6 +221,46 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
             c->l2_scratch_cap = need;
         }
     }
+    return ZZ_OK;
+}
+
+// Level 1: two kernels share the packets of a call through one counter -- k_encode_l1 (table in LDS, at most nine
+// workgroups per CU) on the caller's stream and k_encode_l1g (table in global memory, fills the remaining wave slots)
+// on the context's second stream, forked and joined with events so that the call stays one unit of work on the
+// caller's stream. Either grid covers all packets; workgroups that find the counter exhausted leave at once.
+//   ZZFLATE_L1_MODE (diagnostic): "both" (default), "lds" (only the first kernel, one packet per workgroup by index, as
+//   in round 1), "global" (only the second)
+//   ZZFLATE_L1_PAD_LDS / ZZFLATE_L1G_PAD_LDS (diagnostic): extra dynamic LDS per workgroup of either kernel, which
+//   lowers how many of them a CU holds
+static int launch_level1(zz_ctx* c, const zz_packet_params& pp, hipStream_t st)
+{
+    static const int mode = [] {
+        const char* e = getenv("ZZFLATE_L1_MODE");
+        return !e ? 1 : !strcmp(e, "both") ? 0 : !strcmp(e, "global") ? 2 : 1;
+    }();
+    static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    static const unsigned pad_g = [] { const char* e = getenv("ZZFLATE_L1G_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const uint32_t npk = pp.npk;
+    zz_l1_work w;
+    w.counter = nullptr; w.gtables = nullptr; w.gfree = nullptr; w.gslots = 0;
+    if (mode == 1 || npk < 64) {                           // a handful of packets: nothing to share out
+        hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp, w);
+        return ZZ_OK;
+    }
+    const uint32_t slots = ZZ_L1G_POOL * ZZ_L1G_XCDS;
+    if (!c->d_gtables) {
+        HIPCHK(hipMalloc(&c->d_gtables, (uint64_t)slots * ZZ_HASH_SIZE * sizeof(uint16_t)));
+        HIPCHK(hipMalloc(&c->d_gfree, slots * sizeof(uint32_t)));
+    }
+    HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(c->d_gfree, 0, slots * sizeof(uint32_t), st));
+    w.counter = c->d_work; w.gtables = c->d_gtables; w.gfree = c->d_gfree; w.gslots = slots;
+    HIPCHK(hipEventRecord(c->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+    if (mode != 2) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp, w);
+    hipLaunchKernelGGL(k_encode_l1g, dim3(npk), dim3(ZZ_L1_THREADS), pad_g, c->s_aux, pp, w);
+    HIPCHK(hipEventRecord(c->ev_join, c->s_aux));
+    HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
     return ZZ_OK;
 }
 
@@ -269,9 +322,8 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
             HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
         } else if (level == 1) {
-            // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
-            static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-            hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            int rc1 = launch_level1(c, pp, st);
+            if (rc1) return rc1;
         } else {
             launch_level2(pp, c->l2_scratch, c->d_work, st);
         }
@@ -743,7 +795,7 @@ struct host_sink {
     zz_callback cb = nullptr; void* user = nullptr; std::vector<uint8_t> chunk;
     void raw(const uint8_t* p, uint64_t n)            // header / trailer / a chunk with the reference's own boundaries
     {
-        if (cb) { flush(); if (n) cb(user, p, n); return; }
+        if (cb) { flush(); cb(user, p, n); return; }          // also for 0 bytes (raw deflate: zzflate.cpp:205,221 call regardless)
         put(p, n);
     }
     void put(const uint8_t* p, uint64_t n)            // stream bytes

@@ -80,47 +80,52 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
     return ((three_bytes & 0xFFFFFFu) * 0x00d68664u) >> (32 - ZZ_HASH_BITS);
 }
 
-// per-lane walk info, packed into one VGPR so that the scalar walk needs a single v_readlane per event
+// per-lane walk info, packed into one VGPR so that the scalar walk needs a single v_readlane per event. The match
+// length against the table candidate sits in bits 0..5 (bit 5 always clear) because s_bfm_b64 takes its field size from
+// exactly those bits of its operand: the walk never has to extract it.
 #define ZZ_WI_LENA(i) ((i) & 31u)            // match length vs the table candidate, 16 = "16 or more"
-#define ZZ_WI_LENB(i) (((i) >> 5) & 31u)     // match length vs the nearest earlier same-hash lane
-#define ZZ_WI_QLANE(i) (((i) >> 10) & 63u)   // that lane
-#define ZZ_WI_DUP 0x10000u                   // lane has an earlier same-hash lane in the group
-#define ZZ_WI_HARD 0x20000u                  // its hash occurs more than twice
-#define ZZ_WI_EXTA 0x40000u                  // lenA is "16 or more" and more bytes remain: extend
-#define ZZ_WI_EXTB 0x80000u
-#define ZZ_WI_NEXT(i) (((i) >> 20) & 127u)   // plain matches: first event lane at or after the match end (64 = none)
+#define ZZ_WI_LENB(i) (((i) >> 6) & 31u)     // match length vs the nearest earlier same-hash lane
+#define ZZ_WI_LENB_SHIFT 6
+#define ZZ_WI_QLANE(i) (((i) >> 11) & 63u)   // that lane
+#define ZZ_WI_QLANE_SHIFT 11
+#define ZZ_WI_DUP 0x20000u                   // lane has an earlier same-hash lane in the group
+#define ZZ_WI_HARD 0x40000u                  // its hash occurs more than twice
+#define ZZ_WI_EXTA 0x80000u                  // lenA is "16 or more" and more bytes remain: extend
+#define ZZ_WI_EXTB 0x100000u
+#define ZZ_WI_NEXT_SHIFT 21                  // plain matches: first event lane at or after the match end (0 = none; lane 0 never is one)
 #define ZZ_WI_CAP 16u                        // bytes compared up front (two 8-byte words per lane)
 
-// One hop of the walk's inner loop: a plain match at event lane e (length lenA < 16 against the table candidate),
-// then e = the first event at or after its end. Unrolled twice below (four times measured slower): a taken branch costs about five scalar
-// instructions, so only every other hop pays for one.
-#define ZZ_L1_HOP \
-        "v_readlane_b32 %[inf], %[info], %[e]\n\t" \
-        "s_and_b32 %[len], %[inf], 0x70000\n\t"     /* DUP | HARD | EXTA */ \
-        "s_cmp_eq_u32 %[len], 0\n\t" \
-        "s_cbranch_scc0 4f\n\t" \
-        "s_and_b32 %[len], %[inf], 31\n\t"          /* plain match, length lenA (encoder.cpp:350-354) */ \
-        "s_bitset1_b64 %[mst], %[e]\n\t"            /* a match starts here (encoder.cpp:356) */ \
-        "s_bfm_b64 %[tmp], %[len], %[e]\n\t"        /* lanes e .. e+len-1 */ \
+// One hop of the walk's inner loop: a plain match at event lane EIN (length lenA < 16 against the table candidate),
+// then EOUT = the first event at or after its end. The CU has ONE scalar unit for all its wavefronts (one instruction
+// per cycle: tools/ubench_valu.hip), so with nine parsers per CU every scalar instruction of this loop costs ~16
+// cycles; hence as few as possible: s_and and s_bfe set SCC themselves (no compare), s_bfm takes the length straight
+// from the packed word, the position is only worked out when the loop is left. Unrolled twice with the event lane
+// alternating between two registers, so that only every other hop pays for a taken branch.
+#define ZZ_L1_HOP(EIN, EOUT, FLAGGED) \
+        "v_readlane_b32 %[inf], %[info], " EIN "\n\t" \
+        "s_and_b32 %[len], %[inf], 0xe0000\n\t"    /* DUP | HARD | EXTA: not a plain match */ \
+        "s_cbranch_scc1 " FLAGGED "\n\t" \
+        "s_bitset1_b64 %[mst], " EIN "\n\t"         /* a match starts here (encoder.cpp:356) */ \
+        "s_bfm_b64 %[tmp], %[inf], " EIN "\n\t"     /* lanes EIN .. EIN+lenA-1 (encoder.cpp:361-362) */ \
         "s_or_b64 %[cov], %[cov], %[tmp]\n\t" \
-        "s_add_u32 %[pos], %[e], %[len]\n\t"        /* encoder.cpp:361-362 */ \
-        "s_bfe_u32 %[e], %[inf], 0x70014\n\t"       /* hop to the next event at or after the match end */ \
-        "s_cmp_lt_u32 %[e], 64\n\t"
+        "s_bfe_u32 " EOUT ", %[inf], 0x60015\n\t"   /* hop to the next event at or after the match end; SCC = there is one */
 
 // The inner loop of the walk (encoder.cpp:341-368 replayed over ballot masks), hand-written because scalar code
-// is slow on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip).
+// is slow on this machine (a dependent SALU op ~8 cycles alone and twice that with nine parsers per CU, a taken branch
+// ~40: tools/ubench_scalar.hip, tools/ubench_valu.hip).
 //   E    : lanes that may start a match          info : per-lane packed walk info (ZZ_WI_*), VGPR
 //   pos  : first lane not yet decided            mst  : match-start lanes so far
 //   cov  : lanes inside matches so far           usedB: match starts that matched the in-group candidate
 // Handles, without leaving the loop: plain matches (length < 16 against the table candidate) and lanes with an
 // earlier same-hash lane q in the group (candidate = q if the parse visited it; else the table's, provided no
-// third lane shares the hash). Leaves with pos unchanged at an event it cannot decide (q skipped and 3+ lanes
-// share the hash, or a length of "16 or more" that needs extension); leaves with pos >= 64, or with no event at or after pos, when the group is done.
+// third lane shares the hash). Leaves with pos at an event it cannot decide (q skipped and 3+ lanes share the hash, or
+// a length of "16 or more" that needs extension); leaves with pos >= 64, or with no event at or after pos, when the
+// group is done.
 __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t& pos, uint64_t& mst, uint64_t& cov,
                                              uint64_t& usedB)
 {
     uint64_t tmp;
-    int32_t e;
+    int32_t e, e2;
     uint32_t inf, len, q;
     asm volatile(
         "s_cmp_lt_u32 %[pos], 64\n\t"
@@ -132,8 +137,14 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cmp_lt_i32 %[e], 0\n\t"
         "s_cbranch_scc1 3f\n"
         "9:\n\t"
-        ZZ_L1_HOP "s_cbranch_scc0 3f\n\t"
-        ZZ_L1_HOP "s_cbranch_scc1 9b\n\t"
+        ZZ_L1_HOP("%[e]", "%[e2]", "4f") "s_cbranch_scc0 31f\n\t"
+        ZZ_L1_HOP("%[e2]", "%[e]", "41f") "s_cbranch_scc1 9b\n\t"
+        "s_and_b32 %[len], %[inf], 31\n\t"          // no further event: the position behind the last match
+        "s_add_u32 %[pos], %[e2], %[len]\n\t"
+        "s_branch 3f\n"
+        "31:\n\t"
+        "s_and_b32 %[len], %[inf], 31\n\t"
+        "s_add_u32 %[pos], %[e], %[len]\n\t"
         "s_branch 3f\n"
         "5:\n\t"
         "s_bitset1_b64 %[mst], %[e]\n\t"            // (matches found through the in-group candidate logic)
@@ -143,26 +154,29 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cmp_lt_u32 %[pos], 64\n\t"
         "s_cbranch_scc1 1b\n\t"
         "s_branch 3f\n"
+        "41:\n\t"
+        "s_mov_b32 %[e], %[e2]\n"
         "4:\n\t"
-        "s_bitcmp1_b32 %[inf], 16\n\t"              // not DUP (so EXTA only): leave
+        "s_mov_b32 %[pos], %[e]\n\t"                // every lane below this event is decided
+        "s_bitcmp1_b32 %[inf], 17\n\t"              // not DUP (so EXTA only): leave
         "s_cbranch_scc0 3f\n\t"
-        "s_bfe_u32 %[q], %[inf], 0x6000a\n\t"       // the nearest earlier lane with my hash
+        "s_bfe_u32 %[q], %[inf], 0x6000b\n\t"       // the nearest earlier lane with my hash
         "s_bitcmp1_b64 %[mst], %[q]\n\t"            // visited as a match start?
         "s_cbranch_scc1 6f\n\t"
         "s_bitcmp0_b64 %[cov], %[q]\n\t"            // visited as a literal?
         "s_cbranch_scc1 6f\n\t"
-        "s_bitcmp1_b32 %[inf], 17\n\t"              // skipped, and further lanes share the hash (HARD): leave
+        "s_bitcmp1_b32 %[inf], 18\n\t"              // skipped, and further lanes share the hash (HARD): leave
         "s_cbranch_scc1 3f\n\t"
-        "s_bitcmp1_b32 %[inf], 18\n\t"              // skipped: the table's candidate; EXTA: leave
+        "s_bitcmp1_b32 %[inf], 19\n\t"              // skipped: the table's candidate; EXTA: leave
         "s_cbranch_scc1 3f\n\t"
         "s_and_b32 %[len], %[inf], 31\n\t"
         "s_cmp_lt_u32 %[len], 4\n\t"
         "s_cbranch_scc0 5b\n\t"
         "s_branch 8f\n"
         "6:\n\t"
-        "s_bitcmp1_b32 %[inf], 19\n\t"              // visited: the candidate is lane q (the most recent); EXTB: leave
+        "s_bitcmp1_b32 %[inf], 20\n\t"              // visited: the candidate is lane q (the most recent); EXTB: leave
         "s_cbranch_scc1 3f\n\t"
-        "s_bfe_u32 %[len], %[inf], 0x50005\n\t"
+        "s_bfe_u32 %[len], %[inf], 0x50006\n\t"
         "s_cmp_lt_u32 %[len], 4\n\t"
         "s_cbranch_scc1 8f\n\t"
         "s_bitset1_b64 %[usedB], %[e]\n\t"
@@ -172,7 +186,7 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cmp_lt_u32 %[pos], 64\n\t"
         "s_cbranch_scc1 1b\n"
         "3:\n\t"
-        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e),
+        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e), [e2] "=&s"(e2),
           [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q)
         : [E] "s"(E), [info] "v"(info)
         : "scc");
@@ -214,12 +228,21 @@ __device__ __forceinline__ void l1_group_barrier()
     // the LDS traffic of this wave must have landed; global loads (the next group's prefetch) stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-template <bool SAFE, typename TT, bool SPLIT = false>
 // The block is src[start, n): positions are offsets from `src` (table entries carry over from earlier blocks of the
 // same stream, encoder.cpp:320-327,370), match lengths stop at n.
+//
+// GT = true: the hash table lives in GLOBAL memory (T points there; it stays in the L2 of the workgroup's XCD) instead
+// of LDS, which is what caps a CU at nine packets. Such a workgroup needs 2 KiB of LDS, so seven of them fit beside the
+// nine LDS ones (32 wave slots per CU). The probe is one gather (no speculative insert, so nothing to read back or to
+// restore), lanes that share a hash inside the group are found with a one-bit-per-hash LDS map (`dupmap`, 1 KiB: an
+// atomic OR tells every lane but the first of a set that the bit was already there) and, only then, 13 ballots on the
+// hash itself; after the walk the winners -- per hash the last committed lane -- store their positions. Vector memory
+// operations of one wavefront execute in order and the CU's vector L1 is coherent for the wavefronts of a workgroup
+// (LLVM AMDGPU memory model, gfx90a/gfx942), so the next group's gather sees these stores without a wait.
+template <bool SAFE, typename TT, bool SPLIT = false, bool GT = false>
 __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T, const uint32_t* lcodes,
                                                bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n,
-                                               uint32_t* tokbuf = nullptr, uint32_t start = 0)
+                                               uint32_t* tokbuf = nullptr, uint32_t start = 0, uint32_t* dupmap = nullptr)
 {
     const int lane = lane_id();
     ZZ_PROF_DECL
@@ -238,7 +261,13 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // (1) hash, probe + speculative insert; the candidate's bytes are requested at once
         const uint32_t h = calc_hash3((uint32_t)(w >> 8));              // bytes p+1..p+3 (encoder.cpp:344)
         uint32_t oldraw = 0;                                            // what the slot held (restored if I am skipped)
-        if (active) {
+        uint32_t dupprev = 0;
+        if (GT) {
+            if (active) {
+                oldraw = T[h];                                          // encoder.cpp:345 (global memory, L2-resident)
+                dupprev = atomicOr(&dupmap[h >> 5], 1u << (h & 31));    // was my hash's bit there already?
+            }
+        } else if (active) {
             oldraw = T[h];                                              // encoder.cpp:345
             T[h] = (TT)(p + 1);                                         // encoder.cpp:346
         }
@@ -249,7 +278,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         if (SPLIT && cur != start) l1_group_barrier();                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
-        if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
+        if (GT) { if (active) dupmap[h >> 5] = 0; }                     // the map is clean again for the next group
+        else if (active) rb = T[h];                                     // the slot holds whichever lane wrote last
 
         ZZ_T(1);
         // (1a) the previous group's tokens leave while those loads are in flight
@@ -260,21 +290,26 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // The read-back names the lane whose store landed: the same lane for every member of a set of equal
         // hashes, a different one for different sets -- a 6-bit key, where the hash has 13 bits. Six ballots give
         // every lane the mask of its set, whatever the number of sets (no loop over them).
-        const uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1));
+        const uint64_t lostmask = GT ? ballot(active && ((dupprev >> (h & 31)) & 1)) : ballot(active && rb != (uint32_t)(TT)(p + 1));
         uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
         uint32_t info = 0;
         if (lostmask) {
-            uint32_t W = (uint32_t)lane;
-            if (active) W = (rb - 1u - cur) & 63u;
-            const uint64_t set = wave_match6(W);
+            uint64_t set;
+            if (GT) {
+                set = wave_match_bits<ZZ_HASH_BITS>(h) & actmask;         // lanes past the block's end hold no position
+            } else {
+                uint32_t W = (uint32_t)lane;
+                if (active) W = (rb - 1u - cur) & 63u;
+                set = wave_match6(W);
+            }
             const bool multi = (set & (set - 1)) != 0;
             multimask = ballot(multi);
             if (multi) {
                 myset = set;
                 const uint64_t below = set & ((1ull << lane) - 1);        // earlier lanes with my hash
                 if (below) {
-                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << 10);
+                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << ZZ_WI_QLANE_SHIFT);
                     if (__builtin_popcountll(set) > 2) info |= ZZ_WI_HARD;   // ... shared by more than two lanes
                 }
             }
@@ -304,18 +339,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                 const uint64_t xq = w ^ wq, xq2 = w2 ^ wq2;
                 uint32_t lb = xq ? (uint32_t)__builtin_ctzll(xq) >> 3 : (xq2 ? 8 + ((uint32_t)__builtin_ctzll(xq2) >> 3) : 16);
                 if (lb > capn) lb = capn;
-                info |= lb << 5;
+                info |= lb << ZZ_WI_LENB_SHIFT;
                 if (lb == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTB;
             }
         }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
         const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
-        // a plain match knows where the walk continues: the first event at or after its end (64 = none). With that
+        // a plain match knows where the walk continues: the first event at or after its end (0 = none). With that
         // in the info word the scalar loop hops from match to match without re-scanning the event mask.
         {
             const uint32_t endl = (uint32_t)lane + la;
             const uint64_t m = endl >= 64 ? 0 : (E & (~0ull << endl));
-            info |= (m ? (uint32_t)__builtin_ctzll(m) : 64u) << 20;
+            info |= (m ? (uint32_t)__builtin_ctzll(m) : 0u) << ZZ_WI_NEXT_SHIFT;
         }
 
         ZZ_T(5); ZZ_C(10, 1);
@@ -391,11 +426,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // highest position wins -- the state the serial loop leaves behind
         const bool is_committed = (committed >> lane) & 1;
         ZZ_WAVE_SYNC();
-        if (active && !is_committed) T[h] = (TT)oldraw;
-        if (multimask) {
-            ZZ_WAVE_SYNC();
-            const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
-            if (winner) T[h] = (TT)(p + 1);
+        if (GT) {
+            // nothing was inserted speculatively: the committed lanes insert now, per hash the last one
+            bool wins = is_committed;
+            if (multimask && myset) wins = wins && (((myset & committed) >> lane) >> 1) == 0;
+            if (wins) T[h] = (TT)(p + 1);
+        } else {
+            if (active && !is_committed) T[h] = (TT)oldraw;
+            if (multimask) {
+                ZZ_WAVE_SYNC();
+                const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
+                if (winner) T[h] = (TT)(p + 1);
+            }
         }
         ZZ_WAVE_SYNC();
 
@@ -455,61 +497,72 @@ __device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf
 // and turns the parser's tokens into the bit stream; they meet at one s_barrier per group of 64 positions (see
 // l1_encode_body). Both execute exactly one barrier per group, so the counts always match.
 #define ZZ_L1_THREADS (2 * ZZ_WAVE)
-__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
+#define ZZ_L1_DUPMAP_WORDS (ZZ_HASH_SIZE / 32)
+// what a packet is, for both wavefronts
+struct l1_pk {
+    const uint8_t* src; const uint8_t* end; uint8_t* out;
+    uint64_t off; uint32_t len, n; bool is_final;
+};
+__device__ __forceinline__ l1_pk l1_packet_of(const zz_packet_params& P, uint32_t k)
 {
-    // table + ring + token slots = 17,416 bytes <= 17,920 = 35 LDS granules: NINE workgroups share a CU
-    __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
-    __shared__ uint32_t ring_words[ZZ_RING_WORDS];
-    __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
-
+    l1_pk q;
+    q.off = (uint64_t)k * P.packet_size;
+    q.len = (uint32_t)((P.n - q.off) < P.packet_size ? (P.n - q.off) : P.packet_size);
+    q.is_final = P.last_is_final && k == P.npk - 1;
+    q.n = q.is_final ? q.len : q.len - 1;          // bytes of the compressing AddData (zzflate.cpp:113,116)
+    q.src = P.src + q.off;
+    q.end = P.src + P.n;                           // one past the last readable byte
+    q.out = P.slots + (uint64_t)k * P.slot_stride;
+    return q;
+}
+// ---- parser: cold table (encoder.cpp:533-536), then the block body ------------------------------------------------
+template <bool GT>
+__device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf, uint32_t* dupmap)
+{
     const int lane = lane_id();
-    const uint32_t wave = uniform(threadIdx.x >> 6);
-    const uint32_t k = blockIdx.x;
-    const uint64_t off = (uint64_t)k * P.packet_size;
-    const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
-    const bool is_final = P.last_is_final && k == P.npk - 1;
-    const uint32_t n = is_final ? len : len - 1;   // bytes of the compressing AddData (zzflate.cpp:113,116)
-    const uint8_t* src = P.src + off;
-    const uint8_t* end = P.src + P.n;              // one past the last readable byte
-    uint8_t* out = P.slots + (uint64_t)k * P.slot_stride;
-
-    if (wave == 0) {
-        // ---- parser: cold table (encoder.cpp:533-536), then the block body ------------------------------------
-        uint4* t4 = (uint4*)T;
-        for (int i = lane; i < (int)(sizeof(T) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
-        ZZ_WAVE_SYNC();
-        bitring none;
-        none.ring = nullptr; none.out32 = nullptr; none.bitpos = 0; none.flushed = 0;
-        if (n > 0) {
-            // 16-byte loads may run up to 15 bytes past the packet's last byte: bounds-checked loads wherever that
-            // would leave the shard (decided by bytes, not by packet index: packets may be as short as one byte)
-            if (off + len + 16 > P.n) l1_encode_body<true, uint16_t, true>(P, T, nullptr, none, src, end, n, tokbuf);
-            else l1_encode_body<false, uint16_t, true>(P, T, nullptr, none, src, end, n, tokbuf);
-        }
-        return;
+    const l1_pk q = l1_packet_of(P, k);
+    // the parse is the critical path of the packet, the emitter has slack: the parsing wave goes first in the issue
+    // arbiter (+4.8 % on 1 GiB of text)
+    __builtin_amdgcn_s_setprio(3);
+    uint4* t4 = (uint4*)T;
+    for (int i = lane; i < (int)(ZZ_HASH_SIZE * sizeof(uint16_t) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
+    if (GT) for (int i = lane; i < ZZ_L1_DUPMAP_WORDS; i += ZZ_WAVE) dupmap[i] = 0;
+    ZZ_WAVE_SYNC();
+    bitring none;
+    none.ring = nullptr; none.out32 = nullptr; none.bitpos = 0; none.flushed = 0;
+    if (q.n > 0) {
+        // 16-byte loads may run up to 15 bytes past the packet's last byte: bounds-checked loads wherever that
+        // would leave the shard (decided by bytes, not by packet index: packets may be as short as one byte)
+        if (q.off + q.len + 16 > P.n) l1_encode_body<true, uint16_t, true, GT>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf, 0, dupmap);
+        else l1_encode_body<false, uint16_t, true, GT>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf, 0, dupmap);
     }
-    // ---- emitter ---------------------------------------------------------------------------------------------
+}
+// ---- emitter ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void l1_packet_emitter(const zz_packet_params& P, uint32_t k, uint32_t* ring_words, const uint32_t* tokbuf)
+{
+    const int lane = lane_id();
+    const l1_pk q = l1_packet_of(P, k);
     bitring ring;
-    ring_init(ring, ring_words, out);
+    ring_init(ring, ring_words, q.out);
     if (P.cks_kind == ZZ_CKS_ADLER) {     // while the parser works on its first groups
-        zz_cks c = wave_adler(src, len);
+        zz_cks c = wave_adler(q.src, q.len);
         if (lane == 0) P.cks[k] = c;
     }
-    if (n > 0) {
+    if (q.n > 0) {
         // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
-        ring_append_uniform(ring, (is_final ? 1u : 0u) | (1u << 1), 3);
+        ring_append_uniform(ring, (q.is_final ? 1u : 0u) | (1u << 1), 3);
         l1_emitter(ring, tokbuf);
         // EOB: codes_f[256] = 7 zero bits (encoder.cpp:371)
         ring_append_uniform(ring, 0, 7);
     }
-    if (!is_final) {
+    if (!q.is_final) {
         // SetLevel(0); AddData(e-1, e): one stored byte = byte alignment (zzflate.cpp:118-120,
         // encoder.cpp:482-502): BFINAL=0 BTYPE=00, pad, LEN=1, NLEN=0xFFFE, the byte
         ring_append_uniform(ring, 0, 3);
         ring_pad_to_byte(ring);
         ring_append_uniform(ring, 0xFFFE0001u, 32);
-        ring_append_uniform(ring, src[len - 1], 8);
-    } else if (n == 0) {
+        ring_append_uniform(ring, q.src[q.len - 1], 8);
+    } else if (q.n == 0) {
         // empty final packet (only for empty input): one empty fixed block (D8 divergence, documented)
         ring_append_uniform(ring, 1u | (1u << 1), 3);
         ring_append_uniform(ring, 0, 7);
@@ -518,6 +571,87 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
     if (lane == 0) {
         P.sizes[k] = bytes;
         if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+    }
+}
+
+// How the packets reach the workgroups. Two kernels run side by side on two streams and share the packets of a call:
+// k_encode_l1 (table in LDS: at most nine workgroups per CU, the LDS limit) and k_encode_l1g (table in global memory:
+// 2 KiB of LDS, fills the wave slots the first one leaves free). A workgroup encodes ONE packet, the next one of a
+// counter both kernels draw from, so the split between the two follows from how fast each kind gets through its
+// packets on the CUs the hardware gave it; both grids cover all packets and workgroups that draw nothing leave at once.
+// (A persistent loop per workgroup would do too, but costs registers: values that are invariant across packets get
+// hoisted out of the packet loop and then live through the group loop -- 95 VGPRs instead of 46, which would halve the
+// waves a SIMD can hold.)
+struct zz_l1_work {
+    uint32_t* counter;        // packet = atomicAdd(counter, 1); null: packet = blockIdx.x (one kernel, grid == npk)
+    uint16_t* gtables;        // k_encode_l1g: 16 KiB of table per resident workgroup, `gslots` of them
+    uint32_t* gfree;          // k_encode_l1g: free-list of table slots (a stack of slot numbers) and its top
+    uint32_t gslots;
+};
+__device__ __forceinline__ uint32_t l1_draw_packet(const zz_l1_work& W, uint32_t* slot)
+{
+    if (!W.counter) return blockIdx.x;
+    if (threadIdx.x == 0) *slot = atomicAdd(W.counter, 1u);
+    __syncthreads();
+    return uniform(*slot);
+}
+
+__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P, zz_l1_work W)
+{
+    // table + ring + token slots + 4 = 17,420 bytes <= 17,920 = 35 LDS granules
+    __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
+    __shared__ uint32_t ring_words[ZZ_RING_WORDS];
+    __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
+    __shared__ uint32_t nextk;
+    const uint32_t k = l1_draw_packet(W, &nextk);
+    if (k >= P.npk) return;
+    if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<false>(P, k, T, tokbuf, nullptr);
+    else l1_packet_emitter(P, k, ring_words, tokbuf);
+}
+
+// The table of a k_encode_l1g workgroup is one of `gslots` 16 KiB slots in global memory, taken for the life of the
+// workgroup. The L2 caches of the XCDs are not coherent with each other inside a kernel (gfx942/gfx950: coherence across
+// XCCs needs explicit write-back/invalidate), and a slot is written by one workgroup and re-used by the next, so every
+// XCD has its own pool of slots: a slot's lines only ever live in one L2. A workgroup finds a free slot of its XCD's
+// pool by compare-and-swap on a flag word, starting at a place derived from its packet number, and gives it back when
+// its parser is done (after its last stores have been acknowledged).
+#define ZZ_L1G_POOL 640u                // slots per XCD: 16 workgroups x 32 CUs can be resident, plus slack
+#define ZZ_L1G_XCDS 8u
+__device__ __forceinline__ uint32_t l1g_xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & (ZZ_L1G_XCDS - 1);
+}
+__global__ __launch_bounds__(ZZ_L1_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_l1g(zz_packet_params P, zz_l1_work W)
+{
+    __shared__ uint32_t dupmap[ZZ_L1_DUPMAP_WORDS];
+    __shared__ uint32_t ring_words[ZZ_RING_WORDS];
+    __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
+    __shared__ uint32_t nextk, myslot;
+    if (threadIdx.x == 0) {
+        const uint32_t k = atomicAdd(W.counter, 1u);
+        nextk = k;
+        if (k < P.npk) {
+            const uint32_t base = l1g_xcc_id() * ZZ_L1G_POOL;
+            uint32_t at = (k * 2654435761u) % ZZ_L1G_POOL;
+            for (;;) {                                      // ends: fewer workgroups can be resident than a pool has slots
+                if (atomicCAS(&W.gfree[base + at], 0u, 1u) == 0u) break;
+                at = at + 1 == ZZ_L1G_POOL ? 0 : at + 1;
+            }
+            myslot = base + at;
+        }
+    }
+    __syncthreads();
+    const uint32_t k = uniform(nextk);
+    if (k >= P.npk) return;
+    const uint32_t slot = uniform(myslot);
+    if (uniform(threadIdx.x >> 6) == 0) {
+        l1_packet_parser<true>(P, k, W.gtables + (uint64_t)slot * ZZ_HASH_SIZE, tokbuf, dupmap);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the table's last stores are in the L2
+        if (lane_id() == 0) atomicExch(&W.gfree[slot], 0u);
+    } else {
+        l1_packet_emitter(P, k, ring_words, tokbuf);
     }
 }
 
