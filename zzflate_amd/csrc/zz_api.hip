@@ -306,12 +306,12 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind;
         pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof;
 
+        if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));   // the CRC-32 pass of the gzip container is part of the timed work
         if (cks_kind == ZZ_CKS_CRC) {
             uint32_t g = npk < 2048 ? npk : 2048;   // persistent: table + shift constants are built once per block
             hipLaunchKernelGGL(k_crc32_packets, dim3(g), dim3(ZZ_CRC_THREADS), 0, st, pp);
             pp.cks_kind = ZZ_CKS_NONE;   // the encode kernel must not overwrite the CRC partials
         }
-        if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));
         if (level == 0) {
             const uint64_t total = (uint64_t)(npk - 1) * l0_packet_bytes(P, false) +
                                    l0_packet_bytes((uint32_t)(n - (uint64_t)(npk - 1) * P), last_is_final);

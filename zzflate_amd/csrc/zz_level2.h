@@ -29,6 +29,7 @@
 //                with merged length codes :121-133), or UncompressedFallback (:305-317) when the dynamic block
 //                would not be smaller (:271-274).
 #pragma once
+#include <type_traits>
 #include "zz_checksum.h"
 #include "zz_emit.h"
 #include "zz_level1.h"
@@ -493,15 +494,16 @@ __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t
 
 // One hop of the level-2 walk: a match at candidate lane e if it is "plain" (strong, lengths exact), then e = the
 // first candidate at or after the next probe position. winfo: fwd8 [4:0], need [7:5], "8 or more backward possible"
-// bit 8, "16 or more forward" bit 9, plain bit 10, strong bit 11, next candidate [22:16], lane + fwd8 [29:23].
+// bit 8, "16 or more forward" bit 9, plain bit 10, strong bit 11, next candidate [21:16] (0 = none: lane 0 never
+// follows a match), lane + fwd8 [29:23]. The CU's one scalar unit is shared by all its wavefronts (tools/ubench_valu.hip),
+// so every scalar instruction saved here is saved for the whole CU: s_bfe sets SCC itself, no compare.
 #define ZZ_L2_HOP \
                         "v_readlane_b32 %[inf], %[winfo], %[e]\n\t" \
                         "s_bitcmp1_b32 %[inf], 10\n\t" \
                         "s_cbranch_scc0 5f\n\t"                     /* weak or flagged */ \
                         "s_bitset1_b64 %[ev], %[e]\n\t"             /* a match is found at this probe (:406-407) */ \
                         "s_bfe_u32 %[Brel], %[inf], 0x70017\n\t"    /* backRefEnd (:422), relative to the block */ \
-                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"       /* hop: the first candidate at or after j = backRefEnd + 1 (:424) */ \
-                        "s_cmp_lt_u32 %[e], 64\n\t"
+                        "s_bfe_u32 %[e], %[inf], 0x60010\n\t"       /* hop: the first candidate at or after j = backRefEnd + 1 (:424); 0 = none, and SCC says so */
 
 // ---- token pass ------------------------------------------------------------------------------------------------
 // FirstPass + AddHashEntries over the whole packet (encoder.cpp:217-248, 375-440, 474-480). Returns the number
@@ -641,7 +643,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             {
                 const uint32_t endl = (uint32_t)lane + fwd8 + 1;                  // first lane probed after a match here
                 const uint64_t m = endl >= 64 ? 0 : (Amask & (~0ull << endl));
-                winfo |= (m ? (uint32_t)__builtin_ctzll(m) : 64u) << 16;
+                winfo |= (m ? (uint32_t)__builtin_ctzll(m) : 0u) << 16;
             }
             uint32_t tk = 0;                // start | len << 16, slow tokens only; the others are filled in below
             uint64_t evmask = 0, slowmask = 0;
@@ -688,8 +690,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                         "8:\n\t"
                         "s_bitset1_b64 %[ev], %[e]\n\t"             // a match is found at this probe (:406-407)
                         "s_bfe_u32 %[Brel], %[inf], 0x70017\n\t"
-                        "s_bfe_u32 %[e], %[inf], 0x70010\n\t"
-                        "s_cmp_lt_u32 %[e], 64\n\t"
+                        "s_bfe_u32 %[e], %[inf], 0x60010\n\t"
                         "s_cbranch_scc1 9b\n\t"
                         "s_branch 10b\n"
                         "4:\n\t"
@@ -977,7 +978,12 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
         __syncthreads();
         return uniform(((uint32_t*)covw)[2]);
     };
-    for (uint32_t k = blockIdx.x; k < P.npk; k = next_packet()) {
+    // One packet, as seen by wavefront 0 (W0: parser, code construction, first part of the emission) or by wavefront 1
+    // (helper). Each wavefront runs its OWN packet loop over this body (below): with one loop around both roles,
+    // values that are invariant across packets are hoisted for both roles at once and live through each other's code,
+    // and the kernel does not fit its 96 registers.
+    auto packet = [&](const uint32_t k, auto w0tag) {
+        constexpr bool W0 = decltype(w0tag)::value;
         const uint64_t off = (uint64_t)k * P.packet_size;
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
         const bool is_final = P.last_is_final && k == P.npk - 1;
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
         uint8_t* out = P.slots + (uint64_t)k * P.slot_stride;
 
         __syncthreads();       // both wavefronts are done with the previous packet
-        if (wave == 0) {
+        if (W0) {
             uint4* z = (uint4*)lds;
             for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
         } else {
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
 
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
-            if (wave == 0) {
+            if (W0) {
                 // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
                 if (off + len + 16 > P.n) l2_token_pass<true>(T, hb, src, end, n, before, P.prof);
@@ -1025,7 +1031,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
         }
         uint32_t* share = misc + 4;      // [0] 1 stored / 2 dynamic, [1] first record of the helper's part, [2] bits in front of
                                          // the records, [3] wavefront 0's last (partial) word, [4] the helper's first word
-        if (wave != 0) {
+        if (!W0) {
             if (n == 0 && P.cks_kind == ZZ_CKS_ADLER) {     // (n > 0: summed during the token pass)
                 zz_cks c = wave_adler(src, len);
                 if (lane == 0) P.cks[k] = c;
@@ -1061,7 +1067,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
                     }
                 }
             }
-            continue;
+            return;
         }
         // ---- wavefront 0 alone from here to the end of the packet ------------------------------------------------
         bitring ring;
@@ -1132,7 +1138,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
                 }
                 if (lane == 0) { P.sizes[k] = bytes; share[0] = 1; }
                 __syncthreads();             // (X)
-                continue;
+                return;
             }
 
             // ================= dynamic block ====================================================================
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
                 if (lane == 0) share[3] = (ring.bitpos & 31) ? ring.ring[(ring.bitpos >> 5) & (ZZ_RING_WORDS - 1)] : 0u;
                 __syncthreads();             // (Y)
                 ZZ_T(5);
-                continue;
+                return;
             }
         }
         if (!is_final) {
@@ -1192,6 +1198,12 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
             if (bytes > P.slot_stride) atomicOr(P.err, 1u);
         }
         ZZ_T(5);
+    };
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);      // the parse is the packet's critical path: ahead of the helpers in the issue arbiter
+        for (uint32_t k = blockIdx.x; k < P.npk; k = next_packet()) packet(k, std::true_type());
+    } else {
+        for (uint32_t k = blockIdx.x; k < P.npk; k = next_packet()) packet(k, std::false_type());
     }
     ZZ_PROF_FLUSH(P);
 }
