@@ -39,24 +39,40 @@ SEEDS = {"text": 0x5EED0002, "random": 0x5EED0003, "mix": 0x5EED0004, "log": 0x5
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(sample: bytes, level: int, fmt: int):
-    """Time the reference's CPU encoder (threaded=false per thread, one thread per host core, each on its own
-    slice of the sample). Returns the cpu_baseline JSON object."""
+def cpu_baseline(sample: bytes, level: int, fmt: int, P: int = 32768):
+    """Time the reference's CPU encoder on this box's host cores, one thread per core, each on its own 32 MiB slices of
+    the sample, in two forms:
+      * whole-slice: one ZzFlateEncode(threaded=false) call per slice -- the reference as its own callers run it;
+      * packet mode: the packet recipe (zzflate.cpp:101-125) over the same P-byte ranges the GPU uses -- the same work
+        as the GPU's, and the same bytes: its ratio must equal the GPU line's.
+    Returns the cpu_baseline JSON object (`value` = whole-slice GB/s, `packet_mode` = the second form)."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libzzref.so")
     slice_bytes = 32 << 20
     nslices = max(1, len(sample) // slice_bytes)
     rounds = max(1, (4 * cores) // nslices)   # every core gets ~4 slices => ~15-25 s of CPU work in total
-    u64, ci, vp = ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p
+    u64, u32, ci, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
     if os.path.exists(ref_path):
         L = ctypes.CDLL(ref_path)
         fn = L.zzref_encode_inplace
         fn.restype = u64
         fn.argtypes = [vp, u64, vp, u64, ci, ci, ci]
+        pk = L.zzref_packet
+        pk.restype = u64
+        pk.argtypes = [ci, vp, u64, u64, ci, vp, u64, u32]
         kind = "reference"
 
-        def run(dst, cap, src_ptr, n):
-            return fn(dst, cap, src_ptr, n, fmt, level, 0)
+        def run(dst, cap, at, n, first, last):
+            return fn(dst, cap, base + at, n, fmt, level, 0)
+
+        def run_packets(dst, cap, at, n, first, last):
+            # raw DEFLATE of the packets of this slice (offsets from the start of the sample: level >= 2 extends matches
+            # backward into the bytes in front of a packet); only the very last packet of the sample is final
+            tot = 0
+            for off in range(at, at + n, P):
+                ln = min(P, at + n - off)
+                tot += pk(level, base, off, ln, 1 if (last and off + ln == at + n) else 0, dst, cap, 1)
+            return tot
     else:
         import subprocess
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
@@ -64,37 +80,60 @@ def cpu_baseline(sample: bytes, level: int, fmt: int):
         fn = L.zzo_encode
         fn.restype = u64
         fn.argtypes = [vp, u64, vp, u64, ci, ci]
+        pk = L.zzo_packet
+        pk.restype = u64
+        pk.argtypes = [ci, vp, u64, u64, ci, vp, u64]
         kind = "port"
 
-        def run(dst, cap, src_ptr, n):
-            return fn(dst, cap, src_ptr, n, fmt, level)
+        def run(dst, cap, at, n, first, last):
+            return fn(dst, cap, base + at, n, fmt, level)
+
+        def run_packets(dst, cap, at, n, first, last):
+            tot = 0
+            for off in range(at, at + n, P):
+                ln = min(P, at + n - off)
+                tot += pk(level, base, off, ln, 1 if (last and off + ln == at + n) else 0, dst, cap)
+            return tot
     buf = ctypes.create_string_buffer(sample, len(sample) + 64)   # >= 8 readable bytes after the data
     base = ctypes.addressof(buf)
-    outs = [ctypes.create_string_buffer(2 * slice_bytes + 1024) for _ in range(min(cores, nslices))]
-    todo = list(range(nslices)) * rounds
-    lock = threading.Lock()
-    produced = [0]
+    nthreads = min(cores, nslices * rounds)
+    outs = [ctypes.create_string_buffer(2 * slice_bytes + 1024) for _ in range(nthreads)]
 
-    def worker(w):
-        while True:
-            with lock:
-                if not todo:
-                    return
-                s = todo.pop()
-            r = run(outs[w], 2 * slice_bytes + 1024, base + s * slice_bytes, slice_bytes)
-            with lock:
-                produced[0] += r
-    t0 = time.perf_counter()
-    ths = [threading.Thread(target=worker, args=(w,)) for w in range(len(outs))]
-    [t.start() for t in ths]
-    [t.join() for t in ths]
-    dt = time.perf_counter() - t0
-    total = nslices * rounds * slice_bytes
+    def timed(fn_slice, reps):
+        todo = list(range(nslices)) * reps
+        lock = threading.Lock()
+        produced = [0] * nslices
+
+        def worker(w):
+            while True:
+                with lock:
+                    if not todo:
+                        return
+                    sl = todo.pop()
+                r = fn_slice(outs[w], 2 * slice_bytes + 1024, sl * slice_bytes, slice_bytes, sl == 0, sl == nslices - 1)
+                produced[sl] = r
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=worker, args=(w,)) for w in range(nthreads)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        return nslices * reps * slice_bytes / dt / 1e9, sum(produced), dt
+
+    total_in = nslices * slice_bytes
+    gbs, out_bytes, dt = timed(run, rounds)
+    hl, tl = {0: (2, 4), 1: (10, 8), 2: (0, 0)}[fmt]
+    pgbs, pout, pdt = timed(run_packets, rounds)
     return {
-        "value": round(total / dt / 1e9, 4), "unit": "GB/s", "cores": len(outs), "kind": kind,
+        "value": round(gbs, 4), "unit": "GB/s", "cores": nthreads, "kind": kind,
         "sample": f"{nslices * rounds} x {slice_bytes >> 20} MiB slices ({nslices} distinct) of the same input, level {level}, one "
-                  f"ZzFlateEncode(threaded=false) call per slice, one thread per core; ratio {produced[0] / total:.4f}; "
+                  f"ZzFlateEncode(threaded=false) call per slice, one thread per core; ratio {out_bytes / total_in:.4f}; "
                   f"{dt:.2f} s wall",
+        "packet_mode": {
+            "value": round(pgbs, 4), "unit": "GB/s", "cores": nthreads, "kind": kind,
+            "ratio": round((pout + hl + tl) / total_in, 4),
+            "sample": f"the same slices as {P}-byte packets (the recipe of zzflate.cpp:101-125, one Encoder per packet): the GPU's "
+                      f"work and the GPU's bytes; {pdt:.2f} s wall",
+        },
     }
 
 
@@ -146,6 +185,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="N > 1: 1 = one launch and one gather per step, the gather left in "
                     "flight under the next step's encoding (double-buffered); C > 1 = C pieces per shard, piece c "
                     "travels to rank 0 while piece c+1 is encoded")
+    ap.add_argument("--warm", type=int, default=0, help="level 1: warm window in bytes (0 = cold packets = the reference's threaded "
+                    "stream, the headline; > 0 is the beyond-reference mode of SURVEY.md 8f.3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
@@ -184,6 +225,8 @@ def main():
     fmt = {"zlib": 0, "gzip": 1, "deflate": 2}[args.format]
     ctx = zz.Context(dev)
     ctx.enable_timing(True)
+    if args.warm:
+        ctx.set_warm_window(args.warm)
 
     n = args.mib << 20                 # bytes per rank (weak scaling)
     total_n = n * world
@@ -328,7 +371,7 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu:
         sample_bytes = min(n, 1 << 30)
-        cpu = cpu_baseline(src[:sample_bytes].cpu().numpy().tobytes(), args.level, fmt)
+        cpu = cpu_baseline(src[:sample_bytes].cpu().numpy().tobytes(), args.level, fmt, P)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -362,7 +405,7 @@ def main():
                 "workload": f"{args.mib} MiB synthetic {args.gen} per GPU (zz_generate_device kind={args.gen}, seed "
                             f"{SEEDS[args.gen]:#x}), level {args.level}, {args.format} container, {P}-byte packets, "
                             f"input and output resident in HBM" + ((", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if world > 1 else ""),
-                "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format,
+                "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format, "warm_window": args.warm,
             },
             "roofline": {
                 "bound": "hbm", "kernel": f"k_encode_l{min(args.level, 2)}",

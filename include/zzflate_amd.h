@@ -67,6 +67,15 @@ void zz_ctx_enable_timing(zz_ctx* ctx, int on);
  * negative if timing was off */
 double zz_ctx_last_kernel_ms(zz_ctx* ctx);
 
+/* Warm window (beyond the reference). The reference's threaded mode gives every range a cold hash
+ * table and so loses the matches that would reach back into the previous range; its single Encoder carries the table
+ * across blocks (FixHashTable, encoder.cpp:320-327). With a warm window of `bytes` (0..32768) every level-1 packet
+ * starts with the last `bytes` bytes in front of it hashed into its table (every position, per hash the highest), so
+ * matches may cross packet boundaries while packets still encode independently. The stream is valid DEFLATE but no
+ * longer the reference's threaded stream, hence a separate switch: 0 = off (default). Shards must make the window
+ * available as their halo. Env ZZFLATE_WARM_WINDOW sets it for the host entry points. */
+int zz_ctx_set_warm_window(zz_ctx* ctx, uint32_t bytes);
+
 /* ---- sizes -------------------------------------------------------------------------------------- */
 /* worst-case output bytes for n input bytes (container included) */
 uint64_t zz_bound(uint64_t n, int format, int level, uint32_t packet_size);

@@ -864,19 +864,33 @@ uint64_t zzo_encode_callback(uint8_t* dest, uint64_t cap, const uint8_t* src, ui
     return count + t.pos;
 }
 
-/* zzflate.cpp:101-125: one packet with a fresh (cold) encoder */
-uint64_t zzo_packet(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
-                    uint8_t* out, uint64_t cap)
+/* Warm window -- NOT in the reference (the product's zz_ctx_set_warm_window). The reference's threaded
+ * mode starts every range with a cold table (zzflate.cpp:101-125); its single Encoder carries the table across blocks
+ * (FixHashTable, encoder.cpp:320-327). The warm window sits between the two: before a level-1 packet is parsed, every
+ * position of the last `warm` bytes in front of it (as far as the stream has them) is entered into the table under the
+ * hash of the three bytes behind it (the key CalcHash uses for that position, encoder.cpp:344), in ascending order, so
+ * the highest position per hash stays. This is the executable definition the product's warm mode is tested against. */
+static void prehash(enc_t* e, const uint8_t* s, uint64_t before, uint64_t warm)
+{
+    int64_t W = (int64_t)(before < warm ? before : warm);
+    for (int64_t q = -W; q < 0; ++q) e->table[calc_hash(e, s + q + 1)] = q;
+}
+
+/* zzflate.cpp:101-125: one packet with a fresh encoder (cold table; warm > 0: see prehash) */
+uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
+                         uint8_t* out, uint64_t cap, uint64_t warm)
 {
     enc_t* e = (enc_t*)malloc(sizeof(enc_t));
     const uint8_t* s = base + off;
     const uint8_t* end = s + len;
     if (is_final) {
         enc_init(e, level, out, cap, 1, base, end);
+        if (warm && level == 1) prehash(e, s, off, warm);
         add_data(e, s, end, 1);                              /* :110-113 */
     } else {
         enc_init(e, level, out, cap, 1, base, end - (len ? 1 : 0));
         if (len) {
+            if (warm && level == 1) prehash(e, s, off, warm);
             add_data(e, s, end - 1, 0);                      /* :116 */
             e->level = 0;                                    /* :119 SetLevel(0) */
             e->gend = end;
@@ -889,9 +903,14 @@ uint64_t zzo_packet(int level, const uint8_t* base, uint64_t off, uint64_t len, 
     enc_free(e); free(e);
     return r;
 }
+uint64_t zzo_packet(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
+                    uint8_t* out, uint64_t cap)
+{
+    return zzo_packet_warm(level, base, off, len, is_final, out, cap, 0);
+}
 
-uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uint64_t n, int format,
-                            int level, uint64_t packet_size)
+uint64_t zzo_encode_packets_warm(uint8_t* dest, uint64_t cap, const uint8_t* src, uint64_t n, int format,
+                                 int level, uint64_t packet_size, uint64_t warm)
 {
     uint8_t h[10];
     int hl = header_bytes(format, h);
@@ -902,7 +921,7 @@ uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uin
     for (uint64_t k = 0; k < npk; ++k) {
         uint64_t off = k * packet_size;
         uint64_t len = n - off < packet_size ? n - off : packet_size;
-        uint64_t w = zzo_packet(level, src, off, len, k == npk - 1, dest + count, cap - count);
+        uint64_t w = zzo_packet_warm(level, src, off, len, k == npk - 1, dest + count, cap - count, warm);
         if (w == ZZO_ERROR) return ZZO_ERROR;
         count += w;                                          /* :134-155 in-order join, contiguous */
     }
@@ -912,6 +931,11 @@ uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uin
     bs_flush(&t);
     if (t.overflow) return ZZO_ERROR;
     return count + t.pos;
+}
+uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uint64_t n, int format,
+                            int level, uint64_t packet_size)
+{
+    return zzo_encode_packets_warm(dest, cap, src, n, format, level, packet_size, 0);
 }
 
 /* outputbitstream.h:83-124 driven as zztest/TestBitOutput.cpp does */

@@ -40,6 +40,13 @@ uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uin
 uint64_t zzo_packet(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
                     uint8_t* out, uint64_t cap);
 
+/* The same with a warm window (NOT in the reference; the product's zz_ctx_set_warm_window): at level 1
+ * the last `warm` bytes in front of a packet are entered into its hash table before it is parsed. warm = 0 is above. */
+uint64_t zzo_encode_packets_warm(uint8_t* dest, uint64_t cap, const uint8_t* src, uint64_t n, int format,
+                                 int level, uint64_t packet_size, uint64_t warm);
+uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
+                         uint8_t* out, uint64_t cap, uint64_t warm);
+
 /* checksums */
 uint32_t zzo_adler32(uint32_t start, const uint8_t* p, uint64_t n);             /* adler.cpp:17-43  */
 uint32_t zzo_adler_combine(uint32_t first, uint32_t second, uint64_t len2);    /* adler.cpp:5-15   */

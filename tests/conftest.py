@@ -45,6 +45,8 @@ class Oracle:
         L.zzo_encode.restype = u64; L.zzo_encode.argtypes = [vp, u64, cp, u64, ci, ci]
         L.zzo_encode_packets.restype = u64; L.zzo_encode_packets.argtypes = [vp, u64, cp, u64, ci, ci, u64]
         L.zzo_packet.restype = u64; L.zzo_packet.argtypes = [ci, cp, u64, u64, ci, vp, u64]
+        L.zzo_encode_packets_warm.restype = u64; L.zzo_encode_packets_warm.argtypes = [vp, u64, cp, u64, ci, ci, u64, u64]
+        L.zzo_packet_warm.restype = u64; L.zzo_packet_warm.argtypes = [ci, cp, u64, u64, ci, vp, u64, u64]
         L.zzo_encode_callback.restype = u64
         L.zzo_encode_callback.argtypes = [vp, u64, cp, u64, ci, ci, ctypes.POINTER(u64), ci, ctypes.POINTER(ci)]
         L.zzo_adler32.restype = u32; L.zzo_adler32.argtypes = [u32, cp, u64]
@@ -65,10 +67,10 @@ class Oracle:
         n = self.L.zzo_encode(b, cap, d, len(d), fmt, lvl)
         return None if n == u64(-1).value else b.raw[:n]
 
-    def encode_packets(self, d, fmt, lvl, P=32768):
+    def encode_packets(self, d, fmt, lvl, P=32768, warm=0):
         cap = 2 * len(d) + 1024 + 16 * (len(d) // P + 1)
         b = ctypes.create_string_buffer(cap)
-        n = self.L.zzo_encode_packets(b, cap, d, len(d), fmt, lvl, P)
+        n = self.L.zzo_encode_packets_warm(b, cap, d, len(d), fmt, lvl, P, warm)
         return None if n == u64(-1).value else b.raw[:n]
 
     def packet(self, d, lvl, off, ln, final):

@@ -8,7 +8,7 @@ import zlib
 import pytest
 
 import zzflate_amd as zz
-from conftest import GOLDEN, CORPUS_FILES, SYNTH_KINDS, EDGE_SIZES, synth
+from conftest import GOLDEN, CORPUS_FILES, SYNTH_KINDS, EDGE_SIZES, synth, ROOT as ROOT_DIR
 
 pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(GOLDEN, "golden.json")))
@@ -367,6 +367,72 @@ def test_tiny_packets_at_the_end_of_an_allocation(gpu, oracle, P):
             dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
             w = gpu.ctx.encode(src, n, dst, cap, 2, lvl, P)
             assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 2, lvl, P), (P, n, lvl)
+
+
+@pytest.mark.parametrize("warm", [258, 4096, 32768])
+def test_warm_window_level1(gpu, oracle, corpus, warm):
+    """SURVEY.md 8f.3 (beyond the reference): the last `warm` bytes in front of a packet are hashed into its table before
+    the parse, so matches reach across packet boundaries. Bit-exact with the oracle's restatement of that rule, valid
+    DEFLATE (host zlib and the device decoder), identical through shards and through the host entry points, and on text
+    no larger than the cold-packet stream."""
+    import torch
+    ctx = zz.Context(0)
+    ctx.set_warm_window(warm)
+
+    def enc(d, fmt, P=32768):
+        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        cap = zz.bound(len(d), fmt, 1, P)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = ctx.encode(src, len(d), dst, cap, fmt, 1, P)
+        assert ctx.verify_last() == (0, None)
+        return dst[:w].cpu().numpy().tobytes()
+    for fname in CORPUS_FILES:
+        d = corpus[fname]
+        got = enc(d, 0)
+        assert got == oracle.encode_packets(d, 0, 1, warm=warm), (fname, warm)
+        assert zlib.decompress(got) == d
+    for fname in ("alice29.txt", "lcet10.txt", "plrabn12.txt", "asyoulik.txt"):
+        assert len(enc(corpus[fname], 0)) < len(gpu.encode(corpus[fname], 0, 1)), fname
+    for kind in SYNTH_KINDS + ["longperiod"]:
+        for n, P in ((70000, 32768), (100000, 4096), (33000, 1000), (5000, 777)):
+            d = synth(kind, n, 21)
+            assert enc(d, 2, P) == oracle.encode_packets(d, 2, 1, P, warm=warm), (kind, n, P, warm)
+    # levels other than 1 are untouched by the switch
+    d = corpus["lcet10.txt"]
+    for lvl in (0, 2, 3):
+        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        cap = zz.bound(len(d), 0, lvl)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = ctx.encode(src, len(d), dst, cap, 0, lvl)
+        assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 0, lvl)
+    # shards: the window is the shard's halo
+    buf = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cut = 6 * 32768
+    parts = []
+    for off, n, last in ((0, cut, False), (cut, len(d) - cut, True)):
+        cap = zz.bound(n, 2, 1)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w, _ = ctx.encode_shard(buf.data_ptr() + off, n, dst, cap, halo=off, is_last=last, checksum=zz.Format.Deflate, level=1)
+        assert ctx.verify_last() == (0, None)
+        parts.append(dst[:w].cpu().numpy().tobytes())
+    assert b"".join(parts) == oracle.encode_packets(d, 2, 1, warm=warm)
+    # twice the same call, the same bytes
+    assert enc(d, 1) == enc(d, 1)
+
+
+def test_warm_window_through_the_host_entry_points(gpu, oracle, corpus):
+    """ZZFLATE_WARM_WINDOW for ZzFlateEncode / ZzFlateEncodeToCallback; checked in a child process because the
+    variable is read once. Slabs carry the window in their halo, so the slab pipeline gives the same bytes."""
+    import subprocess, sys
+    code = (
+        "import os, sys; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import zzflate_amd as zz\nfrom conftest import Oracle, CORPUS\n"
+        "d = b''.join(open(os.path.join(CORPUS, f), 'rb').read() for f in ('lcet10.txt', 'alice29.txt', 'plrabn12.txt')) * 3\n"
+        "got = zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 1, True))\n"
+        "assert got == Oracle().encode_packets(d, 0, 1, warm=32768), (len(got),)\nprint('ok')\n") % (ROOT_DIR, ROOT_DIR)
+    env = dict(os.environ, ZZFLATE_WARM_WINDOW="32768", ZZFLATE_SLAB_MIB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("lvl", LEVELS)

@@ -66,11 +66,8 @@ struct zz_ctx {
     zz_verify_params last = {};  bool have_last = false;
     unsigned long long* d_verify = nullptr;
     uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
-    // level 1: the second kernel (hash tables in global memory) runs beside the first on its own stream
-    uint16_t* d_gtables = nullptr; uint32_t* d_gfree = nullptr;
-    hipStream_t s_aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int num_cus = 0;
     uint64_t* d_log = nullptr; uint64_t log_cap_bytes = 0;   // sequential stream, callback form: EnsureOutputLength log
+    uint32_t warm = 0;                   // level 1: warm window in bytes (0 = cold packets, the reference's threaded mode)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_time = false;
@@ -126,10 +123,6 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
-        HIPCHK(hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        HIPCHK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         return ZZ_OK;
     }();
     if (rc) { zz_ctx_destroy(c); return rc; }                            // nothing allocated so far is left behind
@@ -154,10 +147,6 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     if (c->s_enc) (void)hipStreamDestroy(c->s_enc);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     (void)hipHostFree(c->h_res);
-    (void)hipFree(c->d_gtables); (void)hipFree(c->d_gfree);
-    if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -173,7 +162,6 @@ extern "C" int zz_debug_occupancy(int level)
 {
     int nb = -1;
     if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
-    else if (level == 11) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1g, ZZ_L1_THREADS, 0);
     else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
@@ -184,6 +172,16 @@ extern "C" int zz_debug_read_prof(zz_ctx* c, unsigned long long out[16])
     if (!c) return ZZ_E_ARG;
     HIPCHK(hipMemcpy(out, c->d_prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
+    return ZZ_OK;
+}
+// warm window. At level 1 the last `bytes` bytes (at most 32768) in front of every packet -- as far as
+// they exist in the stream: a shard must pass them as its halo -- are hashed into the packet's table before it is parsed,
+// so that matches may reach back across the packet boundary. 0 (the default) gives the reference's threaded stream.
+extern "C" int zz_ctx_set_warm_window(zz_ctx* c, uint32_t bytes)
+{
+    if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
+    if (bytes > 32768) { set_err("warm window must be 0..32768 bytes"); return ZZ_E_ARG; }
+    c->warm = bytes;
     return ZZ_OK;
 }
 extern "C" void zz_ctx_enable_timing(zz_ctx* c, int on) { if (c) { c->timing = on != 0; c->have_time = false; } }
@@ -221,46 +219,6 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
             c->l2_scratch_cap = need;
         }
     }
-    return ZZ_OK;
-}
-
-// Level 1: two kernels share the packets of a call through one counter -- k_encode_l1 (table in LDS, at most nine
-// workgroups per CU) on the caller's stream and k_encode_l1g (table in global memory, fills the remaining wave slots)
-// on the context's second stream, forked and joined with events so that the call stays one unit of work on the
-// caller's stream. Either grid covers all packets; workgroups that find the counter exhausted leave at once.
-//   ZZFLATE_L1_MODE (diagnostic): "both" (default), "lds" (only the first kernel, one packet per workgroup by index, as
-//   in round 1), "global" (only the second)
-//   ZZFLATE_L1_PAD_LDS / ZZFLATE_L1G_PAD_LDS (diagnostic): extra dynamic LDS per workgroup of either kernel, which
-//   lowers how many of them a CU holds
-static int launch_level1(zz_ctx* c, const zz_packet_params& pp, hipStream_t st)
-{
-    static const int mode = [] {
-        const char* e = getenv("ZZFLATE_L1_MODE");
-        return !e ? 1 : !strcmp(e, "both") ? 0 : !strcmp(e, "global") ? 2 : 1;
-    }();
-    static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-    static const unsigned pad_g = [] { const char* e = getenv("ZZFLATE_L1G_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-    const uint32_t npk = pp.npk;
-    zz_l1_work w;
-    w.counter = nullptr; w.gtables = nullptr; w.gfree = nullptr; w.gslots = 0;
-    if (mode == 1 || npk < 64) {                           // a handful of packets: nothing to share out
-        hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp, w);
-        return ZZ_OK;
-    }
-    const uint32_t slots = ZZ_L1G_POOL * ZZ_L1G_XCDS;
-    if (!c->d_gtables) {
-        HIPCHK(hipMalloc(&c->d_gtables, (uint64_t)slots * ZZ_HASH_SIZE * sizeof(uint16_t)));
-        HIPCHK(hipMalloc(&c->d_gfree, slots * sizeof(uint32_t)));
-    }
-    HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(c->d_gfree, 0, slots * sizeof(uint32_t), st));
-    w.counter = c->d_work; w.gtables = c->d_gtables; w.gfree = c->d_gfree; w.gslots = slots;
-    HIPCHK(hipEventRecord(c->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-    if (mode != 2) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp, w);
-    hipLaunchKernelGGL(k_encode_l1g, dim3(npk), dim3(ZZ_L1_THREADS), pad_g, c->s_aux, pp, w);
-    HIPCHK(hipEventRecord(c->ev_join, c->s_aux));
-    HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
     return ZZ_OK;
 }
 
@@ -303,7 +261,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         if (rc) return rc;
         zz_packet_params pp;
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
-        pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind;
+        pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind; pp.warm = level == 1 ? c->warm : 0;
         pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof;
 
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));   // the CRC-32 pass of the gzip container is part of the timed work
@@ -322,8 +280,10 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
             HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
         } else if (level == 1) {
-            int rc1 = launch_level1(c, pp, st);
-            if (rc1) return rc1;
+            // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
+            static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+            if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            else hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
         } else {
             launch_level2(pp, c->l2_scratch, c->d_work, st);
         }
@@ -737,20 +697,29 @@ static int host_devices(std::vector<int>& out)
 // test hook (not in the public header): forget the device list so that the environment is read again
 extern "C" void zz_debug_reset_devices(void) { std::lock_guard<std::mutex> lk(g_mu); g_devices.clear(); }
 
-static int pool_acquire(int device, zz_ctx** out)
+// `held`: contexts of this device the calling host call already holds (ZZFLATE_DEVICES may name a device several
+// times). A call only ever waits for its first context of a device -- it never holds one while waiting for another --
+// so concurrent calls cannot block each other for good.
+static int pool_acquire(int device, int held, zz_ctx** out)
 {
     std::unique_lock<std::mutex> lk(g_mu);
     for (;;) {
         int have = 0;
+        static const uint32_t warm = [] {               // env ZZFLATE_WARM_WINDOW: warm window of the host entry points
+            const char* e = getenv("ZZFLATE_WARM_WINDOW");
+            const long v = e ? atol(e) : 0;
+            return (uint32_t)(v < 0 ? 0 : v > 32768 ? 32768 : v);
+        }();
         for (auto& e : g_pool)
             if (e.c->device == device) {
-                if (!e.busy) { e.busy = true; *out = e.c; return ZZ_OK; }
+                if (!e.busy) { e.busy = true; e.c->warm = warm; *out = e.c; return ZZ_OK; }
                 have++;
             }
-        if (have < ZZ_POOL_PER_DEVICE) {
+        if (have < ZZ_POOL_PER_DEVICE + held) {
             zz_ctx* c = nullptr;
             int rc = zz_ctx_create(device, &c);
             if (rc) return rc;
+            c->warm = warm;
             g_pool.push_back({ c, true });
             *out = c;
             return ZZ_OK;
@@ -766,7 +735,15 @@ static void pool_release(zz_ctx* c)
 struct ctx_lease {                       // contexts borrowed for one host call
     std::vector<zz_ctx*> v;
     ~ctx_lease() { for (zz_ctx* c : v) pool_release(c); }
-    int take(int device) { zz_ctx* c = nullptr; int rc = pool_acquire(device, &c); if (!rc) v.push_back(c); return rc; }
+    int take(int device)
+    {
+        int held = 0;
+        for (zz_ctx* h : v) held += h->device == device;
+        zz_ctx* c = nullptr;
+        int rc = pool_acquire(device, held, &c);
+        if (!rc) v.push_back(c);
+        return rc;
+    }
 };
 
 static int ensure_stage(zz_ctx* c, uint64_t in_bytes, uint64_t out_bytes)
@@ -842,8 +819,8 @@ static uint64_t slab_bytes(uint32_t P)
 }
 
 // bytes of input kept in front of a slab on the device: level >= 2 extends matches backward over at most 258 bytes
-// (encoder.cpp:92-102,404, capped as D11 says) and compares eight at a time
-#define ZZ_SLAB_HALO 4096ull
+// (encoder.cpp:92-102,404, capped as D11 says) and compares eight at a time; a warm window reaches back 32768
+#define ZZ_SLAB_HALO 36864ull
 
 static int ensure_pipe(zz_ctx* c, uint64_t slab, uint64_t slab_bound)
 {

@@ -35,6 +35,7 @@ struct zz_packet_params {
     zz_cks* cks;              // out: checksum partial per packet (may be null when cks_kind == NONE)
     uint32_t* err;            // out: sticky error word (slot overflow etc.)
     unsigned long long* prof; // diagnostic builds (-DZZ_PROF) only: per-phase cycle sums; ignored otherwise
+    uint32_t warm;            // level 1: bytes in front of a packet hashed into its table before the parse (0: cold, the reference)
 };
 
 // ---- the sequential stream's output buffers (outputbitstream.h:171-201) ------------------------------------------

@@ -60,13 +60,13 @@ template <bool SAFE> __device__ __forceinline__ uint32_t ld32(const uint8_t* p, 
 // compare src[pe+from ..) with src[cand+from ..) with the whole wave, 4 bytes per lane; returns the match
 // length (>= from) clamped to maxlen. Only called when the first `from` bytes are known equal.
 template <bool SAFE>
-__device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32_t pe, uint32_t cand,
+__device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32_t pe, int32_t cand,
                                                       uint32_t maxlen, const uint8_t* end, uint32_t from = 8)
 {
     const uint32_t o = from + 4 * (uint32_t)lane_id();
     uint32_t d = 0;
     const bool act = o < maxlen;
-    if (act) d = ld32<SAFE>(src + pe + o, end) ^ ld32<SAFE>(src + cand + o, end);
+    if (act) d = ld32<SAFE>(src + pe + o, end) ^ ld32<SAFE>(src + (cand + (int32_t)o), end);
     const uint64_t neq = ballot(act && d != 0);
     if (!neq) return maxlen;
     const int k = __builtin_ctzll(neq);
@@ -231,18 +231,13 @@ __device__ __forceinline__ void l1_group_barrier()
 // The block is src[start, n): positions are offsets from `src` (table entries carry over from earlier blocks of the
 // same stream, encoder.cpp:320-327,370), match lengths stop at n.
 //
-// GT = true: the hash table lives in GLOBAL memory (T points there; it stays in the L2 of the workgroup's XCD) instead
-// of LDS, which is what caps a CU at nine packets. Such a workgroup needs 2 KiB of LDS, so seven of them fit beside the
-// nine LDS ones (32 wave slots per CU). The probe is one gather (no speculative insert, so nothing to read back or to
-// restore), lanes that share a hash inside the group are found with a one-bit-per-hash LDS map (`dupmap`, 1 KiB: an
-// atomic OR tells every lane but the first of a set that the bit was already there) and, only then, 13 ballots on the
-// hash itself; after the walk the winners -- per hash the last committed lane -- store their positions. Vector memory
-// operations of one wavefront execute in order and the CU's vector L1 is coherent for the wavefronts of a workgroup
-// (LLVM AMDGPU memory model, gfx90a/gfx942), so the next group's gather sees these stores without a wait.
-template <bool SAFE, typename TT, bool SPLIT = false, bool GT = false>
+// BIAS = 32768 (packet mode with a warm window, TT = uint16_t): table entries are position + 1 + BIAS, so that the
+// positions -32768 .. -1 in front of the packet -- hashed into the table before the parse starts -- fit beside the
+// packet's own; candidates further than 32768 back are ignored, as in the sequential stream.
+template <bool SAFE, typename TT, bool SPLIT = false, uint32_t BIAS = 0>
 __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T, const uint32_t* lcodes,
                                                bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n,
-                                               uint32_t* tokbuf = nullptr, uint32_t start = 0, uint32_t* dupmap = nullptr)
+                                               uint32_t* tokbuf = nullptr, uint32_t start = 0)
 {
     const int lane = lane_id();
     ZZ_PROF_DECL
@@ -261,25 +256,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // (1) hash, probe + speculative insert; the candidate's bytes are requested at once
         const uint32_t h = calc_hash3((uint32_t)(w >> 8));              // bytes p+1..p+3 (encoder.cpp:344)
         uint32_t oldraw = 0;                                            // what the slot held (restored if I am skipped)
-        uint32_t dupprev = 0;
-        if (GT) {
-            if (active) {
-                oldraw = T[h];                                          // encoder.cpp:345 (global memory, L2-resident)
-                dupprev = atomicOr(&dupmap[h >> 5], 1u << (h & 31));    // was my hash's bit there already?
-            }
-        } else if (active) {
+        if (active) {
             oldraw = T[h];                                              // encoder.cpp:345
-            T[h] = (TT)(p + 1);                                         // encoder.cpp:346
+            T[h] = (TT)(p + 1 + BIAS);                                  // encoder.cpp:346
         }
-        // the candidate, as pos+1; 0 = none or out of reach (unsigned(distance) <= 32768, encoder.cpp:348)
-        const uint32_t old = (sizeof(TT) == 4 && p + 1 - oldraw > 0x8000u) ? 0 : oldraw;
+        // the candidate, as pos+1 (+BIAS); 0 = none or out of reach (unsigned(distance) <= 32768, encoder.cpp:348)
+        const uint32_t old = ((sizeof(TT) == 4 || BIAS) && p + 1 + BIAS - oldraw > 0x8000u) ? 0 : oldraw;
         uint64_t wc = 0, wc2 = 0;
-        if (active && old) ld128<SAFE>(src + (old - 1), end, wc, wc2);  // encoder.cpp:350
+        if (active && old) ld128<SAFE>(src + (int32_t)(old - 1 - BIAS), end, wc, wc2);  // encoder.cpp:350
         if (SPLIT && cur != start) l1_group_barrier();                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
-        if (GT) { if (active) dupmap[h >> 5] = 0; }                     // the map is clean again for the next group
-        else if (active) rb = T[h];                                     // the slot holds whichever lane wrote last
+        if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
 
         ZZ_T(1);
         // (1a) the previous group's tokens leave while those loads are in flight
@@ -290,19 +278,14 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // The read-back names the lane whose store landed: the same lane for every member of a set of equal
         // hashes, a different one for different sets -- a 6-bit key, where the hash has 13 bits. Six ballots give
         // every lane the mask of its set, whatever the number of sets (no loop over them).
-        const uint64_t lostmask = GT ? ballot(active && ((dupprev >> (h & 31)) & 1)) : ballot(active && rb != (uint32_t)(TT)(p + 1));
+        const uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1 + BIAS));
         uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
         uint32_t info = 0;
         if (lostmask) {
-            uint64_t set;
-            if (GT) {
-                set = wave_match_bits<ZZ_HASH_BITS>(h) & actmask;         // lanes past the block's end hold no position
-            } else {
-                uint32_t W = (uint32_t)lane;
-                if (active) W = (rb - 1u - cur) & 63u;
-                set = wave_match6(W);
-            }
+            uint32_t W = (uint32_t)lane;
+            if (active) W = (rb - 1u - BIAS - cur) & 63u;
+            const uint64_t set = wave_match6(W);
             const bool multi = (set & (set - 1)) != 0;
             multimask = ballot(multi);
             if (multi) {
@@ -378,7 +361,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                 mlen = useB ? ZZ_WI_LENB(inf) : ZZ_WI_LENA(inf);
                 if (mlen >= 4) {
                     if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
-                        const uint32_t cand = useB ? cur + ZZ_WI_QLANE(inf) : readlane(old, e) - 1;
+                        const int32_t cand = useB ? (int32_t)(cur + ZZ_WI_QLANE(inf)) : (int32_t)(readlane(old, e) - 1 - BIAS);
                         mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end, ZZ_WI_CAP);
                         if (lane == e) ovlen = mlen;
                     }
@@ -391,7 +374,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                 uint64_t xe = ~0ull;
                 if (S) {
                     const int c = 63 - __builtin_clzll(S);
-                    cand1 = cur + (uint32_t)c + 1;
+                    cand1 = cur + (uint32_t)c + 1 + BIAS;
                     xe = readlane64(w, e) ^ readlane64(w, c);
                 } else {
                     cand1 = readlane(old, e);
@@ -400,7 +383,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                 mlen = 0;
                 if ((uint32_t)xe == 0 && maxlen >= 4) {
                     if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
-                    else mlen = wave_extend_match<SAFE>(src, pe, cand1 - 1, maxlen, end);
+                    else mlen = wave_extend_match<SAFE>(src, pe, (int32_t)(cand1 - 1 - BIAS), maxlen, end);
                     if (mlen > maxlen) mlen = maxlen;
                 }
                 if (lane == e) { ovlen = mlen; ovcand1 = cand1; }
@@ -426,18 +409,11 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // highest position wins -- the state the serial loop leaves behind
         const bool is_committed = (committed >> lane) & 1;
         ZZ_WAVE_SYNC();
-        if (GT) {
-            // nothing was inserted speculatively: the committed lanes insert now, per hash the last one
-            bool wins = is_committed;
-            if (multimask && myset) wins = wins && (((myset & committed) >> lane) >> 1) == 0;
-            if (wins) T[h] = (TT)(p + 1);
-        } else {
-            if (active && !is_committed) T[h] = (TT)oldraw;
-            if (multimask) {
-                ZZ_WAVE_SYNC();
-                const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
-                if (winner) T[h] = (TT)(p + 1);
-            }
+        if (active && !is_committed) T[h] = (TT)oldraw;
+        if (multimask) {
+            ZZ_WAVE_SYNC();
+            const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
+            if (winner) T[h] = (TT)(p + 1 + BIAS);
         }
         ZZ_WAVE_SYNC();
 
@@ -448,8 +424,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             else {
                 const bool b = (usedB >> lane) & 1;
                 const uint32_t tlen = ovlen ? ovlen : (b ? ZZ_WI_LENB(info) : ZZ_WI_LENA(info));
-                const uint32_t cand1 = ovcand1 ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 : old);
-                ptok = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 - cand1);
+                const uint32_t cand1 = ovcand1 ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 + BIAS : old);
+                ptok = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 + BIAS - cand1);
             }
         }
         cur = next;
@@ -497,7 +473,6 @@ __device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf
 // and turns the parser's tokens into the bit stream; they meet at one s_barrier per group of 64 positions (see
 // l1_encode_body). Both execute exactly one barrier per group, so the counts always match.
 #define ZZ_L1_THREADS (2 * ZZ_WAVE)
-#define ZZ_L1_DUPMAP_WORDS (ZZ_HASH_SIZE / 32)
 // what a packet is, for both wavefronts
 struct l1_pk {
     const uint8_t* src; const uint8_t* end; uint8_t* out;
@@ -516,8 +491,15 @@ __device__ __forceinline__ l1_pk l1_packet_of(const zz_packet_params& P, uint32_
     return q;
 }
 // ---- parser: cold table (encoder.cpp:533-536), then the block body ------------------------------------------------
-template <bool GT>
-__device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf, uint32_t* dupmap)
+// BIAS = 32768: warm window. The reference's threaded mode starts every range with a cold table and
+// so loses the matches that reach back into the previous range (zzflate.cpp:101-125); its single Encoder carries the
+// table across blocks instead (FixHashTable, encoder.cpp:320-327). Here the last P.warm bytes in front of the packet are
+// hashed into the table before the parse starts -- every position, per hash the highest -- so the packet may refer
+// to them (one DEFLATE stream: the window spans packet boundaries). Packets stay independent of each other's parses,
+// so nothing is serialised; the stream is not the reference's threaded stream any more (a separate flag), it is
+// pinned by the oracle's restatement of this very rule and by inflate.
+template <uint32_t BIAS>
+__device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf)
 {
     const int lane = lane_id();
     const l1_pk q = l1_packet_of(P, k);
@@ -526,15 +508,43 @@ __device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint
     __builtin_amdgcn_s_setprio(3);
     uint4* t4 = (uint4*)T;
     for (int i = lane; i < (int)(ZZ_HASH_SIZE * sizeof(uint16_t) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
-    if (GT) for (int i = lane; i < ZZ_L1_DUPMAP_WORDS; i += ZZ_WAVE) dupmap[i] = 0;
     ZZ_WAVE_SYNC();
+    if (BIAS) {
+        const uint64_t before = P.halo + q.off;                       // input bytes of this stream in front of the packet
+        const int32_t W = (int32_t)(before < P.warm ? before : P.warm);
+        // ascending, so that later positions overwrite earlier ones; eight groups of 64 positions per trip with their
+        // loads issued together (one memory round trip per 512 positions instead of one per 64)
+        for (int32_t g = -W; g < 0; g += 8 * ZZ_WAVE) {
+            uint32_t w4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int32_t pos = g + u * ZZ_WAVE + lane;
+                w4[u] = pos < 0 ? load32_safe(q.src + pos + 1, q.end) : 0u;      // key of position pos: bytes pos+1..pos+3 (encoder.cpp:344)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int32_t pos = g + u * ZZ_WAVE + lane;
+                const uint32_t val = (uint32_t)(pos + 1 + (int32_t)BIAS);
+                const uint32_t hh = calc_hash3(w4[u]);
+                bool pend = pos < 0;
+                while (ballot(pend)) {                                  // lanes of one store that share a hash: the highest stays
+                    if (pend) T[hh] = (uint16_t)val;
+                    ZZ_WAVE_SYNC();
+                    uint32_t rb = 0xFFFFFFFFu;
+                    if (pend) rb = T[hh];
+                    pend = pend && rb < val;
+                    ZZ_WAVE_SYNC();
+                }
+            }
+        }
+    }
     bitring none;
     none.ring = nullptr; none.out32 = nullptr; none.bitpos = 0; none.flushed = 0;
     if (q.n > 0) {
         // 16-byte loads may run up to 15 bytes past the packet's last byte: bounds-checked loads wherever that
         // would leave the shard (decided by bytes, not by packet index: packets may be as short as one byte)
-        if (q.off + q.len + 16 > P.n) l1_encode_body<true, uint16_t, true, GT>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf, 0, dupmap);
-        else l1_encode_body<false, uint16_t, true, GT>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf, 0, dupmap);
+        if (q.off + q.len + 16 > P.n) l1_encode_body<true, uint16_t, true, BIAS>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf);
+        else l1_encode_body<false, uint16_t, true, BIAS>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf);
     }
 }
 // ---- emitter ---------------------------------------------------------------------------------------------------------
@@ -574,85 +584,30 @@ __device__ __forceinline__ void l1_packet_emitter(const zz_packet_params& P, uin
     }
 }
 
-// How the packets reach the workgroups. Two kernels run side by side on two streams and share the packets of a call:
-// k_encode_l1 (table in LDS: at most nine workgroups per CU, the LDS limit) and k_encode_l1g (table in global memory:
-// 2 KiB of LDS, fills the wave slots the first one leaves free). A workgroup encodes ONE packet, the next one of a
-// counter both kernels draw from, so the split between the two follows from how fast each kind gets through its
-// packets on the CUs the hardware gave it; both grids cover all packets and workgroups that draw nothing leave at once.
-// (A persistent loop per workgroup would do too, but costs registers: values that are invariant across packets get
-// hoisted out of the packet loop and then live through the group loop -- 95 VGPRs instead of 46, which would halve the
-// waves a SIMD can hold.)
-struct zz_l1_work {
-    uint32_t* counter;        // packet = atomicAdd(counter, 1); null: packet = blockIdx.x (one kernel, grid == npk)
-    uint16_t* gtables;        // k_encode_l1g: 16 KiB of table per resident workgroup, `gslots` of them
-    uint32_t* gfree;          // k_encode_l1g: free-list of table slots (a stack of slot numbers) and its top
-    uint32_t gslots;
-};
-__device__ __forceinline__ uint32_t l1_draw_packet(const zz_l1_work& W, uint32_t* slot)
+// One packet per workgroup, in index order: the hardware dispatcher hands the next packet to whichever CU has room.
+// (Measured and rejected, profiles/README.md: persistent workgroups -- values invariant across packets get hoisted out
+// of the packet loop and live through the group loop, 95 VGPRs instead of 46 --; a second kind of workgroup with its
+// hash table in global memory to fill the wave slots the LDS limit leaves free -- 4x slower per packet: every table
+// access moves a 64-byte sector for two bytes.)
+__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
 {
-    if (!W.counter) return blockIdx.x;
-    if (threadIdx.x == 0) *slot = atomicAdd(W.counter, 1u);
-    __syncthreads();
-    return uniform(*slot);
-}
-
-__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P, zz_l1_work W)
-{
-    // table + ring + token slots + 4 = 17,420 bytes <= 17,920 = 35 LDS granules
+    // table + ring + token slots = 17,416 bytes <= 17,920 = 35 LDS granules: NINE workgroups share a CU
     __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
     __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
-    __shared__ uint32_t nextk;
-    const uint32_t k = l1_draw_packet(W, &nextk);
-    if (k >= P.npk) return;
-    if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<false>(P, k, T, tokbuf, nullptr);
+    const uint32_t k = blockIdx.x;
+    if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<0>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
 }
-
-// The table of a k_encode_l1g workgroup is one of `gslots` 16 KiB slots in global memory, taken for the life of the
-// workgroup. The L2 caches of the XCDs are not coherent with each other inside a kernel (gfx942/gfx950: coherence across
-// XCCs needs explicit write-back/invalidate), and a slot is written by one workgroup and re-used by the next, so every
-// XCD has its own pool of slots: a slot's lines only ever live in one L2. A workgroup finds a free slot of its XCD's
-// pool by compare-and-swap on a flag word, starting at a place derived from its packet number, and gives it back when
-// its parser is done (after its last stores have been acknowledged).
-#define ZZ_L1G_POOL 640u                // slots per XCD: 16 workgroups x 32 CUs can be resident, plus slack
-#define ZZ_L1G_XCDS 8u
-__device__ __forceinline__ uint32_t l1g_xcc_id()
+// the same with a warm window (P.warm > 0)
+__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1w(zz_packet_params P)
 {
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & (ZZ_L1G_XCDS - 1);
-}
-__global__ __launch_bounds__(ZZ_L1_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_l1g(zz_packet_params P, zz_l1_work W)
-{
-    __shared__ uint32_t dupmap[ZZ_L1_DUPMAP_WORDS];
+    __shared__ uint16_t T[ZZ_HASH_SIZE];          // position + 1 + 32768; 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
     __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
-    __shared__ uint32_t nextk, myslot;
-    if (threadIdx.x == 0) {
-        const uint32_t k = atomicAdd(W.counter, 1u);
-        nextk = k;
-        if (k < P.npk) {
-            const uint32_t base = l1g_xcc_id() * ZZ_L1G_POOL;
-            uint32_t at = (k * 2654435761u) % ZZ_L1G_POOL;
-            for (;;) {                                      // ends: fewer workgroups can be resident than a pool has slots
-                if (atomicCAS(&W.gfree[base + at], 0u, 1u) == 0u) break;
-                at = at + 1 == ZZ_L1G_POOL ? 0 : at + 1;
-            }
-            myslot = base + at;
-        }
-    }
-    __syncthreads();
-    const uint32_t k = uniform(nextk);
-    if (k >= P.npk) return;
-    const uint32_t slot = uniform(myslot);
-    if (uniform(threadIdx.x >> 6) == 0) {
-        l1_packet_parser<true>(P, k, W.gtables + (uint64_t)slot * ZZ_HASH_SIZE, tokbuf, dupmap);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the table's last stores are in the L2
-        if (lane_id() == 0) atomicExch(&W.gfree[slot], 0u);
-    } else {
-        l1_packet_emitter(P, k, ring_words, tokbuf);
-    }
+    const uint32_t k = blockIdx.x;
+    if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<32768u>(P, k, T, tokbuf);
+    else l1_packet_emitter(P, k, ring_words, tokbuf);
 }
 
 // The sequential whole-buffer stream of the reference (threaded=false: zzflate.cpp:84-95, one Encoder over the

@@ -78,21 +78,6 @@ __device__ __forceinline__ uint64_t wave_match6(uint32_t key)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// The same for a key of NB bits (the 13-bit hash itself, where no 6-bit stand-in is at hand).
-template <int NB> __device__ __forceinline__ uint64_t wave_match_bits(uint32_t key)
-{
-    const uint32_t nkey = ~key;
-    uint32_t lo = ~0u, hi = ~0u;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-        const uint64_t bm = __ballot((key >> kb) & 1);
-        const uint32_t nm = (uint32_t)(((int32_t)(nkey << (31 - kb))) >> 31);
-        lo = __builtin_amdgcn_bitop3_b32((uint32_t)bm, nm, lo, 0x28);
-        hi = __builtin_amdgcn_bitop3_b32((uint32_t)(bm >> 32), nm, hi, 0x28);
-    }
-    return ((uint64_t)hi << 32) | lo;
-}
-
 // ---- loads ------------------------------------------------------------------------------------
 // gfx950 runs with unaligned global access enabled (amdhsa), so a byte-addressed 4/8-byte load is one
 // global_load_dword/dwordx2. `end` is one past the last readable byte: a load that would cross it is
