@@ -227,6 +227,8 @@ def main():
     ctx.enable_timing(True)
     if args.warm:
         ctx.set_warm_window(args.warm)
+    if args.level > 3:
+        ctx.set_extended_levels(True)      # levels 4..6: beyond the reference (level-2 encoder + warm window), SURVEY.md 8f.2
 
     n = args.mib << 20                 # bytes per rank (weak scaling)
     total_n = n * world
@@ -237,7 +239,7 @@ def main():
     buf = torch.empty(halo + n + 64, dtype=torch.uint8, device="cuda")
     ctx.generate(GEN[args.gen], SEEDS[args.gen], rank * n - halo, buf, halo + n)
     src = buf[halo:]
-    cap = zz.bound(n, 2, args.level, P)
+    cap = zz.bound(n, 2, min(args.level, 3), P)
     shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
     xdev = "cuda" if backend == "nccl" else "cpu"     # where the exchange buffers live
     gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (world > 1 and rank == 0) else None
@@ -371,7 +373,8 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu:
         sample_bytes = min(n, 1 << 30)
-        cpu = cpu_baseline(src[:sample_bytes].cpu().numpy().tobytes(), args.level, fmt, P)
+        # the reference has no level above 3 (zzflate.cpp:201,230): its level 3 is the baseline of the extended levels
+        cpu = cpu_baseline(src[:sample_bytes].cpu().numpy().tobytes(), min(args.level, 3), fmt, P)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -379,11 +382,24 @@ def main():
         comp = state["comp_bytes"]
         algo_bytes = n + comp                      # per launch on this rank: input once + compressed once
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
-        traffic = None
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/collect_profiles.sh; counters
+        # cannot be read inside this run). profiles/traffic.json records which sources it was measured on: it is only
+        # reported while those are the sources this run was built from.
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"level{args.level}_{args.gen}_{args.mib}MiB")
+                import hashlib
+                tj = json.load(open(tpath))
+                hsh = hashlib.sha256()
+                cdir = os.path.join(ROOT, "zzflate_amd", "csrc")
+                for f in sorted(os.listdir(cdir)):
+                    hsh.update(f.encode()); hsh.update(open(os.path.join(cdir, f), "rb").read())
+                if tj.get("source_sha256") == hsh.hexdigest():
+                    traffic = tj.get(f"level{args.level}_{args.gen}_{args.mib}MiB")
+                    traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')}"
+                else:
+                    traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')} is stale (kernel sources changed since): not reported"
             except Exception:
                 traffic = None
         line = {
@@ -408,10 +424,11 @@ def main():
                 "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format, "warm_window": args.warm,
             },
             "roofline": {
-                "bound": "hbm", "kernel": f"k_encode_l{min(args.level, 2)}",
+                "bound": "hbm", "kernel": "k_encode_l2_t" if args.level >= 2 else f"k_encode_l{args.level}",
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
             },
             "cpu_baseline": cpu,
             "check": check,

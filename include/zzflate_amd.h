@@ -69,12 +69,19 @@ double zz_ctx_last_kernel_ms(zz_ctx* ctx);
 
 /* Warm window (beyond the reference). The reference's threaded mode gives every range a cold hash
  * table and so loses the matches that would reach back into the previous range; its single Encoder carries the table
- * across blocks (FixHashTable, encoder.cpp:320-327). With a warm window of `bytes` (0..32768) every level-1 packet
+ * across blocks (FixHashTable, encoder.cpp:320-327). With a warm window of `bytes` (0..32768) every packet (levels >= 1)
  * starts with the last `bytes` bytes in front of it hashed into its table (every position, per hash the highest), so
  * matches may cross packet boundaries while packets still encode independently. The stream is valid DEFLATE but no
  * longer the reference's threaded stream, hence a separate switch: 0 = off (default). Shards must make the window
  * available as their halo. Env ZZFLATE_WARM_WINDOW sets it for the host entry points. */
 int zz_ctx_set_warm_window(zz_ctx* ctx, uint32_t bytes);
+/* Levels beyond the reference (BASELINE configs[3] asks for a "level 6" the reference does not have: it
+ * rejects every level above 3, zzflate.cpp:201,230-234). Off by default, so that the drop-in keeps that error. When on,
+ * levels 4, 5, 6 are accepted by the packet-mode entry points: the level-2 encoder (dynamic Huffman, heap-built codes)
+ * with a warm window of 4, 16, 32 KiB. Not comparable with any reference stream; pinned by the oracle's restatement of
+ * the warm-window rule, by inflate, and by "never larger than level 3". Env ZZFLATE_EXTENDED_LEVELS=1 switches them on
+ * for the host entry points. */
+int zz_ctx_set_extended_levels(zz_ctx* ctx, int on);
 
 /* ---- sizes -------------------------------------------------------------------------------------- */
 /* worst-case output bytes for n input bytes (container included) */

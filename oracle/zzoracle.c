@@ -866,14 +866,17 @@ uint64_t zzo_encode_callback(uint8_t* dest, uint64_t cap, const uint8_t* src, ui
 
 /* Warm window -- NOT in the reference (the product's zz_ctx_set_warm_window). The reference's threaded
  * mode starts every range with a cold table (zzflate.cpp:101-125); its single Encoder carries the table across blocks
- * (FixHashTable, encoder.cpp:320-327). The warm window sits between the two: before a level-1 packet is parsed, every
+ * (FixHashTable, encoder.cpp:320-327). The warm window sits between the two: before a packet (level >= 1) is parsed, every
  * position of the last `warm` bytes in front of it (as far as the stream has them) is entered into the table under the
- * hash of the three bytes behind it (the key CalcHash uses for that position, encoder.cpp:344), in ascending order, so
+ * hash CalcHash uses for that position (the three bytes behind it at level 1, its own three at level >= 2), ascending, so
  * the highest position per hash stays. This is the executable definition the product's warm mode is tested against. */
 static void prehash(enc_t* e, const uint8_t* s, uint64_t before, uint64_t warm)
 {
     int64_t W = (int64_t)(before < warm ? before : warm);
-    for (int64_t q = -W; q < 0; ++q) e->table[calc_hash(e, s + q + 1)] = q;
+    /* the key of a position: level 1 hashes the three bytes BEHIND it (encoder.cpp:344), level >= 2 its own three
+     * (encoder.cpp:388) */
+    const int k = e->level == 1 ? 1 : 0;
+    for (int64_t q = -W; q < 0; ++q) e->table[calc_hash(e, s + q + k)] = q;
 }
 
 /* zzflate.cpp:101-125: one packet with a fresh encoder (cold table; warm > 0: see prehash) */
@@ -885,12 +888,12 @@ uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t 
     const uint8_t* end = s + len;
     if (is_final) {
         enc_init(e, level, out, cap, 1, base, end);
-        if (warm && level == 1) prehash(e, s, off, warm);
+        if (warm && level >= 1) prehash(e, s, off, warm);
         add_data(e, s, end, 1);                              /* :110-113 */
     } else {
         enc_init(e, level, out, cap, 1, base, end - (len ? 1 : 0));
         if (len) {
-            if (warm && level == 1) prehash(e, s, off, warm);
+            if (warm && level >= 1) prehash(e, s, off, warm);
             add_data(e, s, end - 1, 0);                      /* :116 */
             e->level = 0;                                    /* :119 SetLevel(0) */
             e->gend = end;

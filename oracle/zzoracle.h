@@ -40,8 +40,9 @@ uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uin
 uint64_t zzo_packet(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
                     uint8_t* out, uint64_t cap);
 
-/* The same with a warm window (NOT in the reference; the product's zz_ctx_set_warm_window): at level 1
- * the last `warm` bytes in front of a packet are entered into its hash table before it is parsed. warm = 0 is above. */
+/* The same with a warm window (NOT in the reference; the product's zz_ctx_set_warm_window and its extended levels 4..6,
+ * SURVEY.md 8f.2/8f.3): at levels >= 1 the last `warm` bytes in front of a packet are entered into its hash table before
+ * it is parsed. warm = 0 is the function above. */
 uint64_t zzo_encode_packets_warm(uint8_t* dest, uint64_t cap, const uint8_t* src, uint64_t n, int format,
                                  int level, uint64_t packet_size, uint64_t warm);
 uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,

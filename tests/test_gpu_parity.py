@@ -397,14 +397,13 @@ def test_warm_window_level1(gpu, oracle, corpus, warm):
         for n, P in ((70000, 32768), (100000, 4096), (33000, 1000), (5000, 777)):
             d = synth(kind, n, 21)
             assert enc(d, 2, P) == oracle.encode_packets(d, 2, 1, P, warm=warm), (kind, n, P, warm)
-    # levels other than 1 are untouched by the switch
+    # level 0 has nothing to warm
     d = corpus["lcet10.txt"]
-    for lvl in (0, 2, 3):
-        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
-        cap = zz.bound(len(d), 0, lvl)
-        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-        w = ctx.encode(src, len(d), dst, cap, 0, lvl)
-        assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 0, lvl)
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = zz.bound(len(d), 0, 0)
+    dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    w = ctx.encode(src, len(d), dst, cap, 0, 0)
+    assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 0, 0)
     # shards: the window is the shard's halo
     buf = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
     cut = 6 * 32768
@@ -418,6 +417,47 @@ def test_warm_window_level1(gpu, oracle, corpus, warm):
     assert b"".join(parts) == oracle.encode_packets(d, 2, 1, warm=warm)
     # twice the same call, the same bytes
     assert enc(d, 1) == enc(d, 1)
+
+
+def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
+    """levels 4, 5, 6 (off unless switched on) = the level-2 encoder with a warm window of 4, 16, 32 KiB.
+    Bit-exact with the oracle's restatement (level 2 + that window), valid DEFLATE, never larger than level 3 on the
+    text files, and the same window is available at levels 2, 3 through zz_ctx_set_warm_window."""
+    import torch
+    ctx = zz.Context(0)
+
+    def enc(d, fmt, lvl, P=32768):
+        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        cap = zz.bound(len(d), fmt, 2, P)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = ctx.encode(src, len(d), dst, cap, fmt, lvl, P)
+        assert ctx.verify_last() == (0, None)
+        return dst[:w].cpu().numpy().tobytes()
+    d = corpus["alice29.txt"]
+    with pytest.raises(zz.ZzFlateError) as e:       # the reference's error convention until switched on (zzflate.cpp:230)
+        enc(d, 0, 6)
+    assert e.value.code == -1
+    ctx.set_extended_levels(True)
+    with pytest.raises(zz.ZzFlateError):
+        enc(d, 0, 7)
+    for fname in CORPUS_FILES:
+        d = corpus[fname]
+        l3 = gpu.encode(d, 0, 3)
+        for lvl, warm in ((4, 4096), (5, 16384), (6, 32768)):
+            got = enc(d, 0, lvl)
+            assert got == oracle.encode_packets(d, 0, 2, warm=warm), (fname, lvl)
+            assert zlib.decompress(got) == d
+            if fname.endswith(".txt"):
+                assert len(got) < len(l3), (fname, lvl)
+    for kind in SYNTH_KINDS + ["longperiod"]:
+        for n, P in ((70000, 32768), (100000, 4096), (33000, 1000)):
+            d = synth(kind, n, 31)
+            assert enc(d, 2, 6, P) == oracle.encode_packets(d, 2, 2, P, warm=32768), (kind, n, P)
+    ctx.set_extended_levels(False)
+    ctx.set_warm_window(8192)
+    d = corpus["lcet10.txt"]
+    for lvl in (2, 3):
+        assert enc(d, 1, lvl) == oracle.encode_packets(d, 1, lvl, warm=8192)
 
 
 def test_warm_window_through_the_host_entry_points(gpu, oracle, corpus):

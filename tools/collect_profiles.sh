@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collect the per-round profile set on a GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r01_final
+#   bash tools/collect_profiles.sh r02 $(git rev-parse --short HEAD)
 # Kernel-trace/stats and every --pmc group run as separate rocprofv3 passes (never combined); the program is
 # `python3 bench.py ...` directly after `--`. Raw output lands in gpurun_out/prof/<tag>/; tools/summarize_pmc.py
 # turns it into profiles/<tag>_pmc.json, profiles/<tag>_kernel_stats.csv and profiles/traffic.json.
 set -eo pipefail
-TAG=${1:-r01_final}
+TAG=${1:-r02}
+SHA=${2:-unknown}          # commit of the tree being profiled (the GPU box has no .git: pass $(git rev-parse --short HEAD))
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
@@ -20,5 +21,5 @@ run sq_l1     --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_
 run stats_l0  --kernel-trace --stats --output-format csv -d "$OUT/stats_l0" -- $B --steps 5 --warmup 1 --level 0 --gen random --no-extra
 run fetch_l0  --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_l0" -- $B --steps 2 --warmup 1 --level 0 --gen random --no-extra
 run write_l0  --pmc WRITE_SIZE --output-format csv -d "$OUT/write_l0" -- $B --steps 2 --warmup 1 --level 0 --gen random --no-extra
-cd "$R" && python3 tools/summarize_pmc.py "$OUT" "$TAG" --dest "$R/gpurun_out/prof/${TAG}_summary"
+cd "$R" && python3 tools/summarize_pmc.py "$OUT" "$TAG" --dest "$R/gpurun_out/prof/${TAG}_summary" --git-sha "$SHA"
 echo "[collect] done"

@@ -8,7 +8,18 @@ Writes <dest>/<tag>_pmc.json (per-kernel mean of every counter, per dispatch), <
 MI355X_MICROARCH.md prescribes for gfx950 -- FETCH_SIZE counts 128-byte requests as 64, so
 traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (both counters are in KiB).
 """
-import argparse, csv, glob, json, os, re, shutil, collections
+import argparse, csv, glob, hashlib, json, os, re, shutil, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_hash():
+    """SHA-256 over the kernel sources: bench.py reports profiles/traffic.json only while it still describes them"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zzflate_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def short(name):
@@ -31,6 +42,7 @@ def counters(d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src"); ap.add_argument("tag"); ap.add_argument("--dest", default="profiles")
+    ap.add_argument("--git-sha", default="unknown", help="commit the profiled tree was built from")
     a = ap.parse_args()
     os.makedirs(a.dest, exist_ok=True)
     out = {}
@@ -47,8 +59,10 @@ def main():
         f = out.get(fetch, {}).get(kern, {}).get("FETCH_SIZE"); w = out.get(write, {}).get(kern, {}).get("WRITE_SIZE")
         return int((2 * f + w) * 1024) if f is not None and w is not None else None
     traffic["level1_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l1")
-    traffic["level2_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l2")
+    traffic["level2_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l2_t")
     traffic["level0_random_1024MiB"] = t("fetch_l0", "write_l0", "zz::k_encode_l0")
+    traffic["git_sha"] = a.git_sha
+    traffic["source_sha256"] = source_hash()
     json.dump(traffic, open(os.path.join(a.dest, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic))
 

@@ -65,6 +65,7 @@ def _load():
         "zz_ctx_workspace_bytes": (u64, [vp]),
         "zz_ctx_enable_timing": (None, [vp, i32]),
         "zz_ctx_set_warm_window": (i32, [vp, u32]),
+        "zz_ctx_set_extended_levels": (i32, [vp, i32]),
         "zz_ctx_last_kernel_ms": (ctypes.c_double, [vp]),
         "zz_bound": (u64, [u64, i32, i32, u32]),
         "zz_encode": (i32, [vp, pu64, vp, u64, ctypes.POINTER(_CConfig)]),
@@ -222,9 +223,14 @@ class Context:
             return 0
 
     def set_warm_window(self, nbytes):
-        """Level 1: hash the last ``nbytes`` (0..32768) in front of every packet into its table before parsing it, so
+        """Levels >= 1: hash the last ``nbytes`` (0..32768) in front of every packet into its table before parsing it, so
         that matches may reach across packet boundaries (0 = cold packets = the reference's threaded stream)."""
         _check(lib.zz_ctx_set_warm_window(self._h, nbytes))
+
+    def set_extended_levels(self, on=True):
+        """Accept levels 4, 5, 6 (beyond the reference, which rejects them): the level-2 encoder with a warm window of
+        4, 16, 32 KiB. Off by default, so that level > 3 stays the reference's error."""
+        _check(lib.zz_ctx_set_extended_levels(self._h, 1 if on else 0))
 
     def enable_timing(self, on=True):
         lib.zz_ctx_enable_timing(self._h, 1 if on else 0)

@@ -67,7 +67,8 @@ struct zz_ctx {
     unsigned long long* d_verify = nullptr;
     uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
     uint64_t* d_log = nullptr; uint64_t log_cap_bytes = 0;   // sequential stream, callback form: EnsureOutputLength log
-    uint32_t warm = 0;                   // level 1: warm window in bytes (0 = cold packets, the reference's threaded mode)
+    uint32_t warm = 0;                   // levels >= 1: warm window in bytes (0 = cold packets, the reference's threaded mode)
+    bool extended = false;               // levels 4..6 accepted (beyond the reference)
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_time = false;
@@ -162,7 +163,7 @@ extern "C" int zz_debug_occupancy(int level)
 {
     int nb = -1;
     if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
-    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2, ZZ_L2_THREADS, 0);
+    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u>, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
 }
@@ -182,6 +183,14 @@ extern "C" int zz_ctx_set_warm_window(zz_ctx* c, uint32_t bytes)
     if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
     if (bytes > 32768) { set_err("warm window must be 0..32768 bytes"); return ZZ_E_ARG; }
     c->warm = bytes;
+    return ZZ_OK;
+}
+// levels beyond the reference. Off by default, so that the entry points keep the reference's error
+// convention for level > 3; on: levels 4, 5, 6 = the level-2 encoder with a warm window of 4, 16, 32 KiB.
+extern "C" int zz_ctx_set_extended_levels(zz_ctx* c, int on)
+{
+    if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
+    c->extended = on != 0;
     return ZZ_OK;
 }
 extern "C" void zz_ctx_enable_timing(zz_ctx* c, int on) { if (c) { c->timing = on != 0; c->have_time = false; } }
@@ -227,6 +236,14 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
                          uint8_t* d_dst, uint64_t cap, int format, int cks_kind, bool with_container, int level,
                          uint32_t P, hipStream_t st, zz_result* host_res)
 {
+    // Levels 4..6 are beyond the reference (which rejects them, zzflate.cpp:201,230) and only exist when switched on:
+    // the level-2 encoder (dynamic Huffman) with a warm window of 4 / 16 / 32 KiB in front of every packet.
+    uint32_t warm = level >= 1 ? c->warm : 0;
+    if (level >= 4 && level <= 6 && c->extended) {
+        const uint32_t w = level == 4 ? 4096u : level == 5 ? 16384u : 32768u;
+        if (w > warm) warm = w;
+        level = 2;
+    }
     if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
     if (P == 0 || P > ZZ_MAX_PACKET_SIZE) { set_err("packet size must be 1..32768"); return ZZ_E_ARG; }
     if (!d_dst || (!d_src && n)) { set_err("null buffer"); return ZZ_E_ARG; }
@@ -261,7 +278,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         if (rc) return rc;
         zz_packet_params pp;
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
-        pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind; pp.warm = level == 1 ? c->warm : 0;
+        pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind; pp.warm = warm;
         pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof;
 
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));   // the CRC-32 pass of the gzip container is part of the timed work
@@ -710,16 +727,17 @@ static int pool_acquire(int device, int held, zz_ctx** out)
             const long v = e ? atol(e) : 0;
             return (uint32_t)(v < 0 ? 0 : v > 32768 ? 32768 : v);
         }();
+        static const bool ext = [] { const char* e = getenv("ZZFLATE_EXTENDED_LEVELS"); return e && atoi(e) != 0; }();
         for (auto& e : g_pool)
             if (e.c->device == device) {
-                if (!e.busy) { e.busy = true; e.c->warm = warm; *out = e.c; return ZZ_OK; }
+                if (!e.busy) { e.busy = true; e.c->warm = warm; e.c->extended = ext; *out = e.c; return ZZ_OK; }
                 have++;
             }
         if (have < ZZ_POOL_PER_DEVICE + held) {
             zz_ctx* c = nullptr;
             int rc = zz_ctx_create(device, &c);
             if (rc) return rc;
-            c->warm = warm;
+            c->warm = warm; c->extended = ext;
             g_pool.push_back({ c, true });
             *out = c;
             return ZZ_OK;
@@ -1021,7 +1039,9 @@ static int encode_host_sequential(zz_ctx* c, const uint8_t* src, uint64_t n, int
 static int encode_host(const uint8_t* src, uint64_t n, const zz_config* cfg, host_sink& sink)
 {
     const int level = cfg->level;
-    if (level < 0 || level > 3) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
+    static const bool ext = [] { const char* e = getenv("ZZFLATE_EXTENDED_LEVELS"); return e && atoi(e) != 0; }();
+    if (level < 0 || level > (ext ? 6 : 3)) { set_err("level must be 0..3"); return ZZ_E_LEVEL; }
+    if (level > 3 && !cfg->threaded) { set_err("levels 4..6 exist in packet mode only (threaded != 0)"); return ZZ_E_LEVEL; }
     if (!src && n) { set_err("null source"); return ZZ_E_ARG; }
     std::vector<int> devs;
     int rc = host_devices(devs);

@@ -528,7 +528,10 @@ __device__ __forceinline__ uint32_t l2_probe_blocks(uint32_t n)     // trips of 
     return (target + 63) >> 6;
 }
 
-template <bool SAFE>
+// BIAS = 32768: warm window (the extended levels 4..6, see zz_api.hip): table entries are position + 1 + BIAS, the
+// positions -32768 .. -1 in front of the packet were hashed into the table by the caller; candidates 32768 or more back
+// are ignored (encoder.cpp:392).
+template <bool SAFE, uint32_t BIAS = 0>
 __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const uint8_t* src, const uint8_t* end,
                                               uint32_t n, uint64_t before, unsigned long long* prof = nullptr)
 {
@@ -562,13 +565,14 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
         const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
         uint32_t old = 0;
-        if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1); }            // :389-390 / :474-480
+        if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1 + BIAS); }     // :389-390 / :474-480
+        if (BIAS && q + 1 + BIAS - old >= 32768u) old = 0;            // :392 (inside a cold packet every candidate is in reach)
         // the table candidate's bytes are requested at once (a lane whose candidate turns out to sit in this very
         // block takes that lane's registers instead): 16 at the candidate (:399), 8 in front of it (:92-102)
         uint64_t ca = 0, ca2 = 0, cpre = 0;
         if (doProbe && ins && old != 0 && q < batchEnd) {
-            ld128<SAFE>(src + (old - 1), end, ca, ca2);
-            if (before + (old - 1) >= 8) cpre = load64(src + (int64_t)(old - 1) - 8);
+            ld128<SAFE>(src + (int32_t)(old - 1 - BIAS), end, ca, ca2);
+            if ((int64_t)before + (int32_t)(old - 1 - BIAS) >= 8) cpre = load64(src + (int64_t)(int32_t)(old - 1 - BIAS) - 8);
         }
         // next block's own bytes: in flight during the rest of this block
         uint64_t wan = 0, wan2 = 0, wbn = 0;
@@ -586,13 +590,13 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         if (ins) rb = T[h];
         uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
         int inlane = -1;                                              // >= 0: the candidate is that lane of this block
-        if (ballot(ins && rb != q + 1)) {
-            const uint32_t W = ins ? (rb - 1u - base) & 63u : (uint32_t)lane;
+        if (ballot(ins && rb != q + 1 + BIAS)) {
+            const uint32_t W = ins ? (rb - 1u - BIAS - base) & 63u : (uint32_t)lane;
             const uint64_t set = wave_match6(W);
             const uint64_t below = set & ((1ull << lane) - 1);
-            if (ins && below) { inlane = 63 - __builtin_clzll(below); cand1 = base + (uint32_t)inlane + 1; }   // nearest earlier member
+            if (ins && below) { inlane = 63 - __builtin_clzll(below); cand1 = base + (uint32_t)inlane + 1 + BIAS; }   // nearest earlier member
             ZZ_WAVE_SYNC();
-            if (ins && W != (uint32_t)lane && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1);   // last member wins
+            if (ins && W != (uint32_t)lane && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1 + BIAS);   // last member wins
         }
         ZZ_WAVE_SYNC();
         skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
@@ -601,7 +605,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         if (doProbe) {
             // ---- quick compare info for all 64 probes of this block --------------------------------------
             const bool has = ins && cand1 != 0 && q < batchEnd;
-            const uint32_t c = cand1 - 1;
+            const int32_t c = (int32_t)(cand1 - 1 - BIAS);           // may lie in front of the packet (warm window)
             if (ballot(inlane >= 0)) {
                 // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
                 const int sl = inlane >= 0 ? inlane : lane;
@@ -613,7 +617,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             uint32_t fwd8 = 0, bwd8 = 0, room = 0;
             if (has) {
                 const uint64_t x = wa ^ ca, x2 = wa2 ^ ca2;            // 16 bytes at the probe and at the candidate (:399)
-                const uint64_t cb = before + c;                        // bytes in front of the candidate
+                const uint64_t cb = (uint64_t)((int64_t)before + c);   // bytes in front of the candidate
                 room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
                 if (room >= 8) {
                     const uint64_t y = wb ^ cpre;
@@ -719,7 +723,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 const uint32_t bre = readlane(broom, e);
                 uint32_t bw = bre < pe ? bre : pe;
                 {
-                    const uint32_t ce = readlane(c, e);
+                    const int32_t ce = (int32_t)readlane((uint32_t)c, e);
                     if (fwd == 16) fwd = wave_extend_match<SAFE>(src, qe, ce, ZZ_MAX_LEN, end, 16);    // remain(), :64-90
                     const uint32_t re = readlane(room, e);
                     const uint32_t blim = re < pe ? re : pe;
@@ -740,7 +744,8 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             // matches the scalar loop only marked) ---------------------------------------------------------------------
             uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
             if ((evmask >> lane) & 1)
-                slot[lane] = ((slowmask >> lane) & 1) ? ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, q - c, base) : ZZ_L2_HB_PACK_FAST(fwd8, broom, q - c);
+                slot[lane] = ((slowmask >> lane) & 1) ? ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, (uint32_t)((int32_t)q - c), base)
+                                                      : ZZ_L2_HB_PACK_FAST(fwd8, broom, (uint32_t)((int32_t)q - c));
             if (lane == 0) {
                 slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32);
                 slot[66] = (uint32_t)slowmask; slot[67] = (uint32_t)(slowmask >> 32);
@@ -930,7 +935,9 @@ struct zz_l2_params {
 // Two wavefronts per packet. During the token pass wavefront 0 parses (hash table, candidates, the serial walk) and
 // wavefront 1 keeps the books (matches to scratch, bitmap window, symbol counts, finished blocks to records, the
 // Adler-32 sums), one s_barrier per 64-position block. Afterwards wavefront 0 builds the codes and both emit.
-__global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
+// BIAS = 32768: the same with a warm window (P.warm bytes in front of every packet are hashed into its table first).
+template <uint32_t BIAS>
+__global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
     // ---- LDS carve-up: 17,840 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
@@ -1007,10 +1014,38 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2(zz_l2_params Q)
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
             if (W0) {
+                if (BIAS) {
+                    // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
+                    // own three bytes (CalcHash(source + j), :388), ascending, per hash the highest stays
+                    const int32_t Wn = (int32_t)(before < P.warm ? before : P.warm);
+                    for (int32_t g = -Wn; g < 0; g += 8 * ZZ_WAVE) {
+                        uint32_t w4[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int32_t pos = g + u * ZZ_WAVE + lane;
+                            w4[u] = pos < 0 ? load32_safe(src + pos, end) : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int32_t pos = g + u * ZZ_WAVE + lane;
+                            const uint32_t val = (uint32_t)(pos + 1 + (int32_t)BIAS);
+                            const uint32_t hh = calc_hash3(w4[u]);
+                            bool pend = pos < 0;
+                            while (ballot(pend)) {
+                                if (pend) T[hh] = (uint16_t)val;
+                                ZZ_WAVE_SYNC();
+                                uint32_t rb = 0xFFFFFFFFu;
+                                if (pend) rb = T[hh];
+                                pend = pend && rb < val;
+                                ZZ_WAVE_SYNC();
+                            }
+                        }
+                    }
+                }
                 // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
-                if (off + len + 16 > P.n) l2_token_pass<true>(T, hb, src, end, n, before, P.prof);
-                else l2_token_pass<false>(T, hb, src, end, n, before, P.prof);
+                if (off + len + 16 > P.n) l2_token_pass<true, BIAS>(T, hb, src, end, n, before, P.prof);
+                else l2_token_pass<false, BIAS>(T, hb, src, end, n, before, P.prof);
             } else {
                 uint32_t nb = 0, adA = 0;
                 uint64_t adC = 0;
@@ -1217,7 +1252,8 @@ static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, u
 {
     zz_l2_params q; q.pk = pp; q.scratch = scratch; q.work = work;
     (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_encode_l2, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
+    if (pp.warm) hipLaunchKernelGGL(k_encode_l2_t<32768u>, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
+    else hipLaunchKernelGGL(k_encode_l2_t<0u>, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
 }
 
 }  // namespace zz
