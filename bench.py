@@ -187,6 +187,10 @@ def main():
                     "travels to rank 0 while piece c+1 is encoded")
     ap.add_argument("--warm", type=int, default=0, help="level 1: warm window in bytes (0 = cold packets = the reference's threaded "
                     "stream, the headline; > 0 is the beyond-reference mode of SURVEY.md 8f.3)")
+    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2], help="one GPU: calls in flight. 1 (default): every step is one "
+                    "synchronous zz_encode_device call, and the HIP-event kernel time is the kernel's own. 2: two contexts on two "
+                    "streams (zz_encode_device_async / zz_encode_finish), the next step's encode kernel fills the CUs the previous "
+                    "one's last packets leave idle; per-kernel event times then include that sharing, so roofline is not reported")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
@@ -257,12 +261,44 @@ def main():
 
     kernel_ms = []
     state = {}
+    # One GPU, --inflight 2: two calls in flight on two streams (zz_encode_device_async / zz_encode_finish, two contexts,
+    # two output buffers): step i+1's encode kernel fills the CUs that step i's last packets leave idle and runs under
+    # step i's compaction, checksum fold and result copy. Every step is a complete call; the timed region ends when all
+    # are done. --inflight 1 (default): the same code with one lane, i.e. one synchronous call per step.
+    lanes = []
+    if world == 1:
+        for b in range(args.inflight):
+            c2 = ctx if b == 0 else zz.Context(dev)
+            if b:
+                c2.enable_timing(True)
+                if args.warm:
+                    c2.set_warm_window(args.warm)
+                if args.level > 3:
+                    c2.set_extended_levels(True)
+            lanes.append({"ctx": c2, "stream": torch.cuda.Stream(), "dst": shard if b == 0 else torch.empty(cap, dtype=torch.uint8, device="cuda"),
+                          "busy": False})
+
+    def collect(b):
+        ln = lanes[b]
+        if ln["busy"]:
+            w = ln["ctx"].finish()
+            ln["busy"] = False
+            kernel_ms.append(ln["ctx"].last_kernel_ms())
+            state["out_bytes"] = w
+            state["comp_bytes"] = w
+            state["last_lane"] = b
 
     def step():
         if world == 1:
-            w = ctx.encode(src, n, shard, cap, fmt, args.level, P)
-            state["out_bytes"] = w
-            state["comp_bytes"] = w
+            b = state.get("step", 0) % len(lanes)
+            state["step"] = state.get("step", 0) + 1
+            collect(b)                                      # the call that used this context before
+            ln = lanes[b]
+            ln["ctx"].encode_async(src, n, ln["dst"], cap, fmt, args.level, P, stream=ln["stream"].cuda_stream)
+            ln["busy"] = True
+            if len(lanes) == 1:
+                collect(b)                                  # one call at a time: wait for it, as zz_encode_device does
+            return
         elif pipe is None:
             from zzflate_amd import sharded
             b = state.get("step", 0) & 1
@@ -302,6 +338,8 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
 
     def barrier():
+        for b in range(len(lanes)):                         # every call in flight is finished before the clock is read
+            collect(b)
         for b in (0, 1):                                    # every gather has landed before the clock is read
             if pending[b] is not None:
                 tot = pending[b].wait()
@@ -314,8 +352,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kernel_ms.clear()
     barrier()
+    kernel_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -332,7 +370,8 @@ def main():
     check = {}
     torch.cuda.synchronize()
     tv = time.perf_counter()
-    bad, first_bad = ctx.verify_last()
+    vctx = lanes[state.get("last_lane", 0)]["ctx"] if world == 1 else ctx     # the context of the last step
+    bad, first_bad = vctx.verify_last()
     tv = time.perf_counter() - tv
     if world > 1:
         tb = torch.tensor([bad], dtype=torch.int64, device="cuda")
@@ -341,7 +380,7 @@ def main():
     check["device_inflate"] = {"packets": ((n + P - 1) // P) * world, "bad": bad, "seconds_rank0": round(tv, 3)}
     if rank == 0:
         import zlib
-        out_t = shard if world == 1 else gathered_b[state.get("last_buf", 0)]
+        out_t = lanes[state.get("last_lane", 0)]["dst"] if world == 1 else gathered_b[state.get("last_buf", 0)]
         k = min(state["out_bytes"], 96 << 20)
         head = out_t[:k].cpu().numpy().tobytes()
         o = zlib.decompressobj({0: 15, 1: 31, 2: -15}[fmt])
@@ -382,6 +421,8 @@ def main():
         comp = state["comp_bytes"]
         algo_bytes = n + comp                      # per launch on this rank: input once + compressed once
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
+        if world == 1 and len(lanes) > 1:
+            achieved = None                        # event times of overlapping kernels include the sharing of the CUs
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/collect_profiles.sh; counters
         # cannot be read inside this run). profiles/traffic.json records which sources it was measured on: it is only
         # reported while those are the sources this run was built from.
@@ -423,6 +464,7 @@ def main():
                             f"input and output resident in HBM" + ((", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if world > 1 else ""),
                 "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format, "warm_window": args.warm,
             },
+            "calls_in_flight": len(lanes) if world == 1 else None,
             "roofline": {
                 "bound": "hbm", "kernel": "k_encode_l2_t" if args.level >= 2 else f"k_encode_l{args.level}",
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -110,6 +110,14 @@ uint32_t zz_get_packet_size(void);
 int zz_encode_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                      int format, int level, uint32_t packet_size, void* hip_stream);
 
+/* The same call in two halves: zz_encode_device_async enqueues the whole pipeline on `hip_stream` and returns without
+ * waiting; zz_encode_finish waits for it and returns the length (or the error, as zz_encode_device). With two contexts
+ * on two streams, call i+1 can be enqueued before call i is finished: its encode kernel fills the CUs call i's last
+ * packets leave idle and runs under call i's compaction and result copy. One enqueued call per context at a time. */
+int zz_encode_device_async(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, int format, int level,
+                           uint32_t packet_size, void* hip_stream);
+int zz_encode_finish(zz_ctx* ctx, uint64_t* out_len);
+
 /* The reference's sequential whole-buffer stream (threaded == 0, zzflate.cpp:84-95) for device-resident data, in
  * the form ZzFlateEncode gives it (caller-owned buffer of `cap` bytes): level 0 (stored blocks of 65535 bytes,
  * parallel), level 1 (fixed-Huffman blocks; ONE for the whole input when (cap - header - 1) * 8 / 9 - 8 >= n, else as

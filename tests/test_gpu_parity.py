@@ -369,6 +369,38 @@ def test_tiny_packets_at_the_end_of_an_allocation(gpu, oracle, P):
             assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 2, lvl, P), (P, n, lvl)
 
 
+def test_two_calls_in_flight(gpu, oracle, corpus):
+    """zz_encode_device_async / zz_encode_finish: two contexts on two streams, the second call enqueued before the first is
+    finished; same bytes as the synchronous call, errors come out of finish, a context refuses a second call."""
+    torch = gpu.torch
+    d0, d1 = corpus["lcet10.txt"] * 8, corpus["kennedy.xls"] * 3
+    ctxs = [zz.Context(0), zz.Context(0)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for lvl in LEVELS:
+        bufs = []
+        for i, d in enumerate((d0, d1)):
+            src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+            cap = zz.bound(len(d), 1, lvl)
+            dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            bufs.append((src, dst, cap, d))
+        torch.cuda.synchronize()
+        for i, (src, dst, cap, d) in enumerate(bufs):
+            ctxs[i].encode_async(src, len(d), dst, cap, 1, lvl, stream=streams[i].cuda_stream)
+        with pytest.raises(zz.ZzFlateError):
+            ctxs[0].encode(bufs[0][0], len(d0), bufs[0][1], bufs[0][2], 1, lvl)      # one call per context at a time
+        for i, (src, dst, cap, d) in enumerate(bufs):
+            w = ctxs[i].finish()
+            assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d, 1, lvl), (lvl, i)
+            assert ctxs[i].verify_last() == (0, None)
+    src, dst, cap, d = bufs[0]
+    ctxs[0].encode_async(src, len(d), dst, 1000, 1, 1, stream=streams[0].cuda_stream)   # too small: reported by finish
+    with pytest.raises(zz.ZzFlateError) as e:
+        ctxs[0].finish()
+    assert e.value.code == -2
+    with pytest.raises(zz.ZzFlateError):
+        ctxs[0].finish()                                                               # nothing enqueued
+
+
 @pytest.mark.parametrize("warm", [258, 4096, 32768])
 def test_warm_window_level1(gpu, oracle, corpus, warm):
     """SURVEY.md 8f.3 (beyond the reference): the last `warm` bytes in front of a packet are hashed into its table before

@@ -73,6 +73,8 @@ def _load():
         "zz_set_packet_size": (i32, [u32]),
         "zz_get_packet_size": (u32, []),
         "zz_encode_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, u32, vp]),
+        "zz_encode_device_async": (i32, [vp, vp, u64, vp, u64, i32, i32, u32, vp]),
+        "zz_encode_finish": (i32, [vp, pu64]),
         "zz_encode_stream_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, vp]),
         "zz_encode_stream_chunks_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, pu64, u32, ctypes.POINTER(u32), vp]),
         "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
@@ -247,6 +249,17 @@ class Context:
         st = self._stream() if stream is None else stream
         _check(lib.zz_encode_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
                                     int(level), packet_size, st))
+        return out.value
+
+    def encode_async(self, src, n, dst, cap, format=Format.Zlib, level=1, packet_size=DEFAULT_PACKET, stream=None):
+        """Enqueue ``encode`` on ``stream`` without waiting; ``finish()`` returns the byte count. One call per context at a
+        time: use two contexts on two streams to keep two calls in flight."""
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_device_async(self._h, self._ptr(src), n, self._ptr(dst), cap, int(format), int(level), packet_size, st))
+
+    def finish(self):
+        out = ctypes.c_uint64(0)
+        _check(lib.zz_encode_finish(self._h, ctypes.byref(out)))
         return out.value
 
     def encode_stream(self, src, n, dst, cap, format=Format.Zlib, level=1, stream=None):

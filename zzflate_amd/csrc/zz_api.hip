@@ -67,6 +67,9 @@ struct zz_ctx {
     unsigned long long* d_verify = nullptr;
     uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
     uint64_t* d_log = nullptr; uint64_t log_cap_bytes = 0;   // sequential stream, callback form: EnsureOutputLength log
+    // a call that has been enqueued but not waited for (zz_encode_device_async .. zz_encode_finish)
+    struct { bool active = false; hipStream_t st = nullptr; uint32_t npk = 0; int level = 0; bool whole = false; } pend;
+    uint32_t* h_err = nullptr;           // pinned: the kernels' sticky error word
     uint32_t warm = 0;                   // levels >= 1: warm window in bytes (0 = cold packets, the reference's threaded mode)
     bool extended = false;               // levels 4..6 accepted (beyond the reference)
     bool timing = false;
@@ -122,6 +125,7 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&c->h_err, 4 * sizeof(uint32_t), hipHostMallocDefault));
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
         return ZZ_OK;
@@ -147,7 +151,7 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_enc) (void)hipStreamDestroy(c->s_enc);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
-    (void)hipHostFree(c->h_res);
+    (void)hipHostFree(c->h_res); (void)hipHostFree(c->h_err);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -232,10 +236,13 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
 }
 
 // The common pipeline. with_container: write header/trailer (whole stream) or not (shard).
+static int encode_finish(zz_ctx* c, zz_result* host_res);
+// `host_res` == nullptr: enqueue only (zz_encode_device_async); the caller collects with encode_finish.
 static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t halo, bool last_is_final,
                          uint8_t* d_dst, uint64_t cap, int format, int cks_kind, bool with_container, int level,
                          uint32_t P, hipStream_t st, zz_result* host_res)
 {
+    if (c->pend.active) { set_err("a call enqueued with zz_encode_device_async has not been finished on this context"); return ZZ_E_ARG; }
     // Levels 4..6 are beyond the reference (which rejects them, zzflate.cpp:201,230) and only exist when switched on:
     // the level-2 encoder (dynamic Huffman) with a warm window of 4 / 16 / 32 KiB in front of every packet.
     uint32_t warm = level >= 1 ? c->warm : 0;
@@ -318,20 +325,28 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
                        c->d_cks_total, n, c->d_res);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(zz_result), hipMemcpyDeviceToHost, st));
-    uint32_t kerr = 0;
-    HIPCHK(hipMemcpyAsync(&kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *host_res = *c->h_res;
-    if (kerr) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
-    if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    HIPCHK(hipMemcpyAsync(c->h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (npk) {
-        zz_verify_params& v = c->last;
+        zz_verify_params& v = c->last;     // completed by encode_finish (stream_bytes)
         v.src = d_src; v.n = n; v.halo = halo; v.packet_size = P; v.npk = npk; v.last_is_final = last_is_final ? 1 : 0;
-        v.stream = d_dst + hl; v.stream_bytes = host_res->stream_bytes;
+        v.stream = d_dst + hl; v.stream_bytes = 0;
         v.offsets = level ? c->offsets : nullptr; v.sizes = level ? c->sizes : nullptr;
         v.l0_stride = (uint32_t)l0_packet_bytes(P, false);
-        c->have_last = true;
     }
+    c->pend.active = true; c->pend.st = st; c->pend.npk = npk; c->pend.level = level; c->pend.whole = with_container;
+    if (!host_res) return ZZ_OK;
+    return encode_finish(c, host_res);
+}
+// wait for the call encode_common enqueued on this context and collect its result
+static int encode_finish(zz_ctx* c, zz_result* host_res)
+{
+    if (!c->pend.active) { set_err("nothing enqueued on this context"); return ZZ_E_ARG; }
+    c->pend.active = false;
+    HIPCHK(hipStreamSynchronize(c->pend.st));
+    *host_res = *c->h_res;
+    if (c->h_err[0]) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
+    if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    if (c->pend.npk) { c->last.stream_bytes = host_res->stream_bytes; c->have_last = true; }
     return ZZ_OK;
 }
 
@@ -573,6 +588,31 @@ extern "C" int zz_encode_device(zz_ctx* c, const void* d_src, uint64_t n, void* 
     zz_result r;
     int rc = encode_common(c, (const uint8_t*)d_src, n, 0, true, (uint8_t*)d_dst, cap, format, cks_kind_for(format),
                            true, level, P, (hipStream_t)hip_stream, &r);
+    if (rc) return rc;
+    *out_len = r.total_bytes;
+    return ZZ_OK;
+}
+
+// The same call in two halves, so that several calls -- on several contexts, each with its own stream -- can be in flight:
+// the next call's encode kernel then fills the CUs the previous one's last packets leave idle, and runs under its
+// compaction, checksum fold and result copy. zz_encode_device_async enqueues everything and returns; zz_encode_finish
+// waits for it and hands out the length (or the error). One call per context at a time; source, destination and the
+// stream must stay alive in between.
+extern "C" int zz_encode_device_async(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, int format, int level,
+                                      uint32_t P, void* hip_stream)
+{
+    if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    if (P == 0) P = ZZ_DEFAULT_PACKET;
+    return encode_common(c, (const uint8_t*)d_src, n, 0, true, (uint8_t*)d_dst, cap, format, cks_kind_for(format), true, level, P,
+                         (hipStream_t)hip_stream, nullptr);
+}
+extern "C" int zz_encode_finish(zz_ctx* c, uint64_t* out_len)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
+    zz_result r;
+    int rc = encode_finish(c, &r);
     if (rc) return rc;
     *out_len = r.total_bytes;
     return ZZ_OK;
