@@ -216,8 +216,13 @@ def main():
     # (LOCAL_RANK mod device_count) and the exchange runs over gloo on host copies of the shards
     backend = os.environ.get("ZZ_BENCH_BACKEND", "nccl")
     ndev = max(1, torch.cuda.device_count())
+    # ZZ_BENCH_FORCE_DIST=1: take the distributed path even with one rank (RCCL init, all-gather, all-reduce, barrier
+    # and the assembly on rank 0 run on a one-GPU box; the send/recv of the gather needs a second GPU)
+    multi = world > 1 or os.environ.get("ZZ_BENCH_FORCE_DIST") == "1"
     dev = local % ndev if world > 1 else 0
-    if world > 1:
+    if multi:
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev)
@@ -246,15 +251,15 @@ def main():
     cap = zz.bound(n, 2, min(args.level, 3), P)
     shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
     xdev = "cuda" if backend == "nccl" else "cpu"     # where the exchange buffers live
-    gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (world > 1 and rank == 0) else None
+    gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (multi and rank == 0) else None
     # step-overlapped mode: a second pair of buffers, so that step i's gather can still be in flight during step i+1
-    shard_b = [shard, torch.empty(cap, dtype=torch.uint8, device="cuda") if world > 1 else None]
-    gathered_b = [gathered, torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (world > 1 and rank == 0) else None]
+    shard_b = [shard, torch.empty(cap, dtype=torch.uint8, device="cuda") if multi else None]
+    gathered_b = [gathered, torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (multi and rank == 0) else None]
     pending = [None, None]
-    C = max(1, args.chunks) if world > 1 else 1
+    C = max(1, args.chunks) if multi else 1
     assert n % (C * P) == 0, "--mib must split into --chunks packet-aligned pieces"
     pipe = None
-    if world > 1 and C > 1:
+    if multi and C > 1:
         from zzflate_amd import sharded
         pipe = sharded.PipelinedGather(dist, fmt, cap, torch.device(xdev))
     torch.cuda.synchronize()
@@ -266,7 +271,7 @@ def main():
     # step i's compaction, checksum fold and result copy. Every step is a complete call; the timed region ends when all
     # are done. --inflight 1 (default): the same code with one lane, i.e. one synchronous call per step.
     lanes = []
-    if world == 1:
+    if (not multi):
         for b in range(args.inflight):
             c2 = ctx if b == 0 else zz.Context(dev)
             if b:
@@ -289,7 +294,7 @@ def main():
             state["last_lane"] = b
 
     def step():
-        if world == 1:
+        if (not multi):
             b = state.get("step", 0) % len(lanes)
             state["step"] = state.get("step", 0) + 1
             collect(b)                                      # the call that used this context before
@@ -346,7 +351,7 @@ def main():
                 pending[b] = None
                 if rank == 0:
                     state["out_bytes"] = tot
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -359,7 +364,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -370,17 +375,17 @@ def main():
     check = {}
     torch.cuda.synchronize()
     tv = time.perf_counter()
-    vctx = lanes[state.get("last_lane", 0)]["ctx"] if world == 1 else ctx     # the context of the last step
+    vctx = lanes[state.get("last_lane", 0)]["ctx"] if (not multi) else ctx     # the context of the last step
     bad, first_bad = vctx.verify_last()
     tv = time.perf_counter() - tv
-    if world > 1:
+    if multi:
         tb = torch.tensor([bad], dtype=torch.int64, device="cuda")
         dist.all_reduce(tb)
         bad = int(tb.item())
     check["device_inflate"] = {"packets": ((n + P - 1) // P) * world, "bad": bad, "seconds_rank0": round(tv, 3)}
     if rank == 0:
         import zlib
-        out_t = lanes[state.get("last_lane", 0)]["dst"] if world == 1 else gathered_b[state.get("last_buf", 0)]
+        out_t = lanes[state.get("last_lane", 0)]["dst"] if (not multi) else gathered_b[state.get("last_buf", 0)]
         k = min(state["out_bytes"], 96 << 20)
         head = out_t[:k].cpu().numpy().tobytes()
         o = zlib.decompressobj({0: 15, 1: 31, 2: -15}[fmt])
@@ -390,7 +395,7 @@ def main():
         check["inflate_prefix_bytes"] = len(dec)
 
     extra = {}
-    if rank == 0 and world == 1 and not args.no_extra and args.level == 1:
+    if rank == 0 and (not multi) and not args.no_extra and args.level == 1:
         # the config's "dynamic Huffman" wording means reference level 2: side measurement
         try:
             cap2 = zz.bound(n, fmt, 2, P)
@@ -421,7 +426,7 @@ def main():
         comp = state["comp_bytes"]
         algo_bytes = n + comp                      # per launch on this rank: input once + compressed once
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
-        if world == 1 and len(lanes) > 1:
+        if (not multi) and len(lanes) > 1:
             achieved = None                        # event times of overlapping kernels include the sharing of the CUs
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/collect_profiles.sh; counters
         # cannot be read inside this run). profiles/traffic.json records which sources it was measured on: it is only
@@ -453,7 +458,7 @@ def main():
             "ms_per_step": round(ms, 3),
             "higher_is_better": True,
             "scaling": "weak",
-            "backend": (("rccl" if backend == "nccl" else backend) + f" (torch.distributed {backend}, world size {dist.get_world_size()})") if world > 1 else None,
+            "backend": (("rccl" if backend == "nccl" else backend) + f" (torch.distributed {backend}, world size {dist.get_world_size()})") if multi else None,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
@@ -461,10 +466,10 @@ def main():
             "config": {
                 "workload": f"{args.mib} MiB synthetic {args.gen} per GPU (zz_generate_device kind={args.gen}, seed "
                             f"{SEEDS[args.gen]:#x}), level {args.level}, {args.format} container, {P}-byte packets, "
-                            f"input and output resident in HBM" + ((", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if world > 1 else ""),
+                            f"input and output resident in HBM" + ((", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if multi else ""),
                 "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format, "warm_window": args.warm,
             },
-            "calls_in_flight": len(lanes) if world == 1 else None,
+            "calls_in_flight": len(lanes) if (not multi) else None,
             "roofline": {
                 "bound": "hbm", "kernel": "k_encode_l2_t" if args.level >= 2 else f"k_encode_l{args.level}",
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -477,7 +482,7 @@ def main():
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -110,3 +110,18 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_rccl_path_with_one_rank(tmp_path):
+    """The distributed path of bench.py on RCCL with the one rank a one-GPU box can host: communicator creation, the
+    size/checksum all-gather, the all-reduce of the step time, barriers and the assembly on rank 0 run over RCCL (backend
+    "nccl" on ROCm); only the send/recv of the gather itself needs a second GPU (covered over gloo above)."""
+    env = dict(os.environ, ZZ_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ZZ_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--mib", "64",
+                        "--no-cpu", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["backend"].startswith("rccl") and "world size 1" in line["backend"]
+    assert line["check"]["device_inflate"]["bad"] == 0 and line["check"]["inflate_prefix_ok"]

@@ -1,4 +1,5 @@
-"""Extended seeded fuzz against the oracle (manual; the pytest suite runs a 120-case version):
+"""Extended seeded fuzz against the oracle (manual; the pytest suite runs a 120-case version): packet mode (cold, warm
+window, extended levels), the sequential stream into roomy and tight destinations, the callback form's chunks.
 python tools/fuzz_gpu.py [cases] [seed]"""
 import os, random, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,14 +30,58 @@ for it in range(cases):
     P = rng.choice([32768, 32768, 32768, 16384, 8192, 4096, 2048, 1024, 1000, 777, rng.randint(1, 32768)])
     lvl = rng.randint(0, 3); fmt = rng.randint(0, 2)
     src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
-    cap = zz.bound(len(d), fmt, lvl, P)
-    dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-    w = ctx.encode(src, len(d), dst, cap, fmt, lvl, P)
-    got = dst[:w].cpu().numpy().tobytes()
-    want = o.encode_packets(d, fmt, lvl, P)
-    if got != want or zlib.decompressobj(WB[fmt]).decompress(got) != d:
-        bad += 1
-        print("MISMATCH", it, kind, len(d), P, lvl, fmt, flush=True)
+    mode = it % 4
+    if mode == 3 and len(d) > 0:
+        # the reference's single-Encoder stream (threaded = false) into a tight or roomy destination, or in chunks
+        if rng.random() < 0.5:
+            cap = rng.choice([2 * len(d) + 1024, max(200, len(d)), max(200, len(d) * rng.randint(40, 99) // 100)])
+            want = o.encode(d, fmt, lvl, cap=cap)
+            ok_ref = False
+            try:
+                ok_ref = zlib.decompressobj(WB[fmt]).decompress(want) == d
+            except zlib.error:
+                pass
+            dst = torch.zeros(cap + 64, dtype=torch.uint8, device="cuda")
+            try:
+                w = ctx.encode_stream(src, len(d), dst, cap, fmt, lvl)
+                got = dst[:w].cpu().numpy().tobytes()
+            except zz.ZzFlateError:
+                got = None
+            if (ok_ref and got != want) or (not ok_ref and got is not None and lvl == 1):
+                bad += 1
+                print("MISMATCH stream", it, kind, len(d), cap, lvl, fmt, got is None, flush=True)
+        else:
+            want, sizes = o.encode_callback(d, fmt, lvl)
+            cap = 2 * len(d) + 4096
+            dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+            w, chunks = ctx.encode_stream_chunks(src, len(d), dst, cap, fmt, lvl)
+            got = dst[:w].cpu().numpy().tobytes()
+            valid = True
+            try:
+                valid = zlib.decompressobj(WB[fmt]).decompress(want) == d
+            except zlib.error:
+                valid = False
+            if valid and (got != want or chunks != sizes[1:-1]):
+                bad += 1
+                print("MISMATCH chunks", it, kind, len(d), lvl, fmt, flush=True)
+    else:
+        # packet mode; every other case with a warm window or an extended level
+        warm = rng.choice([0, 0, 258, 1000, 4096, 32768]) if mode >= 1 else 0
+        elvl = lvl
+        if mode == 2 and rng.random() < 0.4:
+            elvl = rng.choice([4, 5, 6]); warm = 0
+        ctx.set_warm_window(warm)
+        ctx.set_extended_levels(elvl > 3)
+        cap = zz.bound(len(d), fmt, min(elvl, 3), P)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = ctx.encode(src, len(d), dst, cap, fmt, elvl, P)
+        got = dst[:w].cpu().numpy().tobytes()
+        ow = {4: 4096, 5: 16384, 6: 32768}.get(elvl, warm)
+        want = o.encode_packets(d, fmt, 2 if elvl > 3 else lvl, P, warm=ow)
+        vb, _ = ctx.verify_last() if len(d) else (0, None)
+        if got != want or zlib.decompressobj(WB[fmt]).decompress(got) != d or vb:
+            bad += 1
+            print("MISMATCH", it, kind, len(d), P, elvl, fmt, warm, vb, flush=True)
     if it % 100 == 99: print(f"{it + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
 print("bad", bad)
 sys.exit(1 if bad else 0)
