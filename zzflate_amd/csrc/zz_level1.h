@@ -75,6 +75,15 @@ __device__ __forceinline__ uint32_t wave_extend_match(const uint8_t* src, uint32
     return len < maxlen ? len : maxlen;
 }
 
+// number of equal leading bytes of two 16-byte strings given as the XOR of their two little-endian words, 16 = all.
+// Branch-free on purpose: every exec-mask region costs three scalar instructions, and the CU's one scalar unit is the
+// scarce resource (tools/ubench_valu.hip).
+__device__ __forceinline__ uint32_t equal_bytes16(uint64_t x, uint64_t x2)
+{
+    const uint32_t c1 = x ? (uint32_t)__builtin_ctzll(x) : 64u;
+    const uint32_t c2 = x2 ? (uint32_t)__builtin_ctzll(x2) : 64u;
+    return (c1 < 64u ? c1 : 64u + c2) >> 3;
+}
 __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encoder.cpp:11-17
 {
     return ((three_bytes & 0xFFFFFFu) * 0x00d68664u) >> (32 - ZZ_HASH_BITS);
@@ -244,30 +253,38 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
     uint32_t grp = 0;
     uint32_t cur = start;
     uint32_t ptok = 0;                                                    // previous group's tokens
+    // Packet mode (SPLIT): lanes past the block's end take part in the table accesses and loads like everyone else --
+    // they read clamped addresses, hash whatever they read and scribble over table slots, but only in the packet's
+    // last group, after which the table is dead; they can never commit, and `left` = 0 keeps them from matching. A lane
+    // mask around each of those accesses would cost three scalar instructions apiece in every group. The sequential
+    // stream (table carried from block to block) keeps the masks.
+    constexpr bool MASKED = !SPLIT;
     uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position
-    if (start + (uint32_t)lane < n) ld128<SAFE>(src + start + lane, end, w, w2);
+    if (MASKED) { if (start + (uint32_t)lane < n) ld128<SAFE>(src + start + lane, end, w, w2); }
+    else ld128<SAFE>(src + (start + (uint32_t)lane < n ? start + (uint32_t)lane : n - 1), end, w, w2);
     while (cur < n) {
         const uint32_t nact = (n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE;
-        const uint64_t actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1);
         const uint32_t p = cur + lane;
         const bool active = lane < (int)nact;
+        const bool tact = MASKED ? active : true;                       // takes part in table accesses
 
         ZZ_T(0);
         // (1) hash, probe + speculative insert; the candidate's bytes are requested at once
         const uint32_t h = calc_hash3((uint32_t)(w >> 8));              // bytes p+1..p+3 (encoder.cpp:344)
         uint32_t oldraw = 0;                                            // what the slot held (restored if I am skipped)
-        if (active) {
+        if (tact) {
             oldraw = T[h];                                              // encoder.cpp:345
             T[h] = (TT)(p + 1 + BIAS);                                  // encoder.cpp:346
         }
         // the candidate, as pos+1 (+BIAS); 0 = none or out of reach (unsigned(distance) <= 32768, encoder.cpp:348)
         const uint32_t old = ((sizeof(TT) == 4 || BIAS) && p + 1 + BIAS - oldraw > 0x8000u) ? 0 : oldraw;
-        uint64_t wc = 0, wc2 = 0;
-        if (active && old) ld128<SAFE>(src + (int32_t)(old - 1 - BIAS), end, wc, wc2);  // encoder.cpp:350
+        // every lane loads (lanes without a candidate: the packet's first bytes, result unused) -- no lane mask to set up
+        uint64_t wc, wc2;
+        ld128<SAFE>(src + (old ? (int32_t)(old - 1 - BIAS) : (int32_t)start), end, wc, wc2);  // encoder.cpp:350
         if (SPLIT && cur != start) l1_group_barrier();                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
-        if (active) rb = T[h];                                          // the slot holds whichever lane wrote last
+        if (tact) rb = T[h];                                            // the slot holds whichever lane wrote last
 
         ZZ_T(1);
         // (1a) the previous group's tokens leave while those loads are in flight
@@ -303,14 +320,10 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // (2) lengths against both possible candidates, capped at 16 ("16 or more")
         const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
         const uint32_t capn = left < ZZ_WI_CAP ? left : ZZ_WI_CAP;
-        uint64_t x = ~0ull;
-        uint32_t la = 0;
-        if (active && old) {
-            x = w ^ wc;
-            const uint64_t x2 = w2 ^ wc2;
-            la = x ? (uint32_t)__builtin_ctzll(x) >> 3 : (x2 ? 8 + ((uint32_t)__builtin_ctzll(x2) >> 3) : 16);
-            if (la > capn) la = capn;
-        }
+        const uint64_t x = w ^ wc;                                      // (only looked at where there is a candidate)
+        uint32_t la = equal_bytes16(x, w2 ^ wc2);
+        if (la > capn) la = capn;
+        if (!(active && old)) la = 0;
         info |= la;
         if (la == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTA;
         if (multimask) {
@@ -318,13 +331,11 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             const int ql = (info & ZZ_WI_DUP) ? (int)ZZ_WI_QLANE(info) : lane;
             const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), ql) << 32) | (uint32_t)__shfl((int)w, ql);
             const uint64_t wq2 = ((uint64_t)(uint32_t)__shfl((int)(w2 >> 32), ql) << 32) | (uint32_t)__shfl((int)w2, ql);
-            if (info & ZZ_WI_DUP) {
-                const uint64_t xq = w ^ wq, xq2 = w2 ^ wq2;
-                uint32_t lb = xq ? (uint32_t)__builtin_ctzll(xq) >> 3 : (xq2 ? 8 + ((uint32_t)__builtin_ctzll(xq2) >> 3) : 16);
-                if (lb > capn) lb = capn;
-                info |= lb << ZZ_WI_LENB_SHIFT;
-                if (lb == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTB;
-            }
+            uint32_t lb = equal_bytes16(w ^ wq, w2 ^ wq2);
+            if (lb > capn) lb = capn;
+            if (!(info & ZZ_WI_DUP)) lb = 0;
+            info |= lb << ZZ_WI_LENB_SHIFT;
+            if (lb == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTB;
         }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
         const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
@@ -399,17 +410,19 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         }
         ZZ_T(6);
         // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
-        const uint64_t committed = (actmask & ~cov & (pos >= 64 ? ~0ull : ((1ull << pos) - 1))) | mst;
+        // (the walk leaves 1 <= pos, and pos <= nact wherever nact < 64: every lane below pos is an active one)
+        const uint64_t committed = (~cov & (~0ull >> (64u - (pos < 64u ? pos : 64u)))) | mst;
         const uint32_t next = cur + pos;
         // next group's bytes: in flight while this group is repaired
         uint64_t wnext = 0, wnext2 = 0;
-        if (next + (uint32_t)lane < n) ld128<SAFE>(src + next + lane, end, wnext, wnext2);
+        if (MASKED) { if (next + (uint32_t)lane < n) ld128<SAFE>(src + next + lane, end, wnext, wnext2); }
+        else if (next < n) ld128<SAFE>(src + (next + (uint32_t)lane < n ? next + (uint32_t)lane : n - 1), end, wnext, wnext2);
 
         // (4) table repair: skipped lanes restore the old entry; among committed lanes sharing a hash the
         // highest position wins -- the state the serial loop leaves behind
         const bool is_committed = (committed >> lane) & 1;
         ZZ_WAVE_SYNC();
-        if (active && !is_committed) T[h] = (TT)oldraw;
+        if (tact && !is_committed) T[h] = (TT)oldraw;
         if (multimask) {
             ZZ_WAVE_SYNC();
             const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
@@ -418,15 +431,13 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_WAVE_SYNC();
 
         // (5) this group's tokens, emitted by the next iteration
-        ptok = 0;
-        if (is_committed) {
-            if (!((mst >> lane) & 1)) ptok = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
-            else {
-                const bool b = (usedB >> lane) & 1;
-                const uint32_t tlen = ovlen ? ovlen : (b ? ZZ_WI_LENB(info) : ZZ_WI_LENA(info));
-                const uint32_t cand1 = ovcand1 ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 + BIAS : old);
-                ptok = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 + BIAS - cand1);
-            }
+        {   // (selects, not branches: the values are cheap and a lane-mask region is not)
+            const bool b = (usedB >> lane) & 1;
+            const uint32_t tlen = ovlen ? ovlen : (b ? ZZ_WI_LENB(info) : ZZ_WI_LENA(info));
+            const uint32_t cand1 = ovcand1 ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 + BIAS : old);
+            const uint32_t tmatch = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 + BIAS - cand1);
+            const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
+            ptok = is_committed ? (((mst >> lane) & 1) ? tmatch : tlit) : 0u;
         }
         cur = next;
         if (SPLIT) {
@@ -434,7 +445,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             // sits in the next trip, behind the wait for the table read that trip needs anyway
             uint32_t* slot = tokbuf + (grp & 1) * ZZ_L1_TOKSLOT;
             slot[lane] = ptok;
-            if (lane == 0) slot[64] = next >= n;
+            slot[64] = next >= n;                   // (every lane stores the same word: no lane mask to set up)
             grp++;
         }
         if (sizeof(TT) == 4 && ring.flushed >= (1u << 24)) {
