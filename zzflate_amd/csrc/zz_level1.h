@@ -130,30 +130,32 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 // third lane shares the hash). Leaves with pos at an event it cannot decide (q skipped and 3+ lanes share the hash, or
 // a length of "16 or more" that needs extension); leaves with pos >= 64, or with no event at or after pos, when the
 // group is done.
-__device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t& pos, uint64_t& mst, uint64_t& cov,
+// `nact`: lanes of the group that hold positions; when no event is left, pos comes back as max(pos, nact): the rest are
+// literals and the group is done (the caller need not look at E again).
+__device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t nact, uint32_t& pos, uint64_t& mst, uint64_t& cov,
                                              uint64_t& usedB)
 {
     uint64_t tmp;
     int32_t e, e2;
     uint32_t inf, len, q;
     asm volatile(
-        "s_cmp_lt_u32 %[pos], 64\n\t"
-        "s_cbranch_scc0 3f\n"
-        "1:\n\t"
+        "1:\n\t"                                    // (pos < 64 here: the caller leaves its loop otherwise)
         "s_lshl_b64 %[tmp], -1, %[pos]\n\t"
         "s_and_b64 %[tmp], %[tmp], %[E]\n\t"
         "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first event at or after pos (-1: none)
         "s_cmp_lt_i32 %[e], 0\n\t"
-        "s_cbranch_scc1 3f\n"
+        "s_cbranch_scc1 30f\n"
         "9:\n\t"
         ZZ_L1_HOP("%[e]", "%[e2]", "4f") "s_cbranch_scc0 31f\n\t"
         ZZ_L1_HOP("%[e2]", "%[e]", "41f") "s_cbranch_scc1 9b\n\t"
         "s_and_b32 %[len], %[inf], 31\n\t"          // no further event: the position behind the last match
         "s_add_u32 %[pos], %[e2], %[len]\n\t"
-        "s_branch 3f\n"
+        "s_branch 30f\n"
         "31:\n\t"
         "s_and_b32 %[len], %[inf], 31\n\t"
-        "s_add_u32 %[pos], %[e], %[len]\n\t"
+        "s_add_u32 %[pos], %[e], %[len]\n"
+        "30:\n\t"
+        "s_max_u32 %[pos], %[pos], %[nact]\n\t"     // the rest of the group are literals
         "s_branch 3f\n"
         "5:\n\t"
         "s_bitset1_b64 %[mst], %[e]\n\t"            // (matches found through the in-group candidate logic)
@@ -197,7 +199,7 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "3:\n\t"
         : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e), [e2] "=&s"(e2),
           [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q)
-        : [E] "s"(E), [info] "v"(info)
+        : [E] "s"(E), [info] "v"(info), [nact] "s"(nact)
         : "scc");
 }
 
@@ -355,11 +357,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events
         uint32_t pos = 0;
         for (;;) {
-            l1_fast_walk(E, info, pos, mst, cov, usedB);
+            l1_fast_walk(E, info, nact, pos, mst, cov, usedB);
             if (pos >= nact) break;
-            const uint64_t Er = E & (~0ull << pos);
-            if (!Er) { pos = nact; break; }
-            const int e = __builtin_ctzll(Er);
+            const int e = (int)pos;                                     // the walk stopped AT an event it cannot decide
             ZZ_C(11, 1);
             const uint64_t probed = ~cov | mst;                         // lanes below e the parse has visited
             const uint32_t inf = readlane(info, e);
@@ -431,13 +431,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_WAVE_SYNC();
 
         // (5) this group's tokens, emitted by the next iteration
-        {   // (selects, not branches: the values are cheap and a lane-mask region is not)
-            const bool b = (usedB >> lane) & 1;
-            const uint32_t tlen = ovlen ? ovlen : (b ? ZZ_WI_LENB(info) : ZZ_WI_LENA(info));
-            const uint32_t cand1 = ovcand1 ? ovcand1 : (b ? cur + ZZ_WI_QLANE(info) + 1 + BIAS : old);
+        {   // (masks, not branches: the values are cheap and a lane-mask region is three scalar instructions)
+            const uint32_t mB = 0u - (uint32_t)((usedB >> lane) & 1);          // all ones where the in-group candidate matched
+            const uint32_t la_ = ZZ_WI_LENA(info), ca_ = old;
+            const uint32_t tl = la_ ^ ((la_ ^ ZZ_WI_LENB(info)) & mB);
+            const uint32_t cn = ca_ ^ ((ca_ ^ (cur + ZZ_WI_QLANE(info) + 1 + BIAS)) & mB);
+            const uint32_t mL = 0u - (uint32_t)(ovlen != 0), mC = 0u - (uint32_t)(ovcand1 != 0);
+            const uint32_t tlen = tl ^ ((tl ^ ovlen) & mL);
+            const uint32_t cand1 = cn ^ ((cn ^ ovcand1) & mC);
             const uint32_t tmatch = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 + BIAS - cand1);
             const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
-            ptok = is_committed ? (((mst >> lane) & 1) ? tmatch : tlit) : 0u;
+            const uint32_t mM = 0u - (uint32_t)((mst >> lane) & 1);
+            ptok = (tlit ^ ((tlit ^ tmatch) & mM)) & (0u - (uint32_t)is_committed);
         }
         cur = next;
         if (SPLIT) {
