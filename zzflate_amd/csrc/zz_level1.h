@@ -207,20 +207,44 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
 #define ZZ_TOK_MATCH 0x80000000u
 #define ZZ_TOK_LIT 0x40000000u
 
+// Fixed-Huffman fragment of one token, by arithmetic and selects only (RFC 1951 3.2.5/3.2.6; the reference's tables
+// lcodes_f / dcodes_f / codes_f, fixedhuffmanluts.cpp:5-55, hold the same values): no lane-mask region, i.e. no scalar
+// instruction, in the emitter's inner loop.
+__device__ __forceinline__ void l1_token_bits(uint32_t tok, uint32_t& bits, uint32_t& nb)
+{
+    // literal: 0..143 -> 8 bits 00110000+, 144..255 -> 9 bits 110010000+   (codes_f[*sourcePtr], encoder.cpp:367)
+    const uint32_t byte = tok & 0xFF;
+    const uint32_t lnb = byte < 144 ? 8u : 9u;
+    const uint32_t lbits = __builtin_bitreverse32(byte + (byte < 144 ? 0x30u : 0x100u)) >> (32 - lnb);
+    // match: merged length code (symbol code, then its extra bits), 5-bit distance code, distance extra bits
+    // (lcodes_f[matchLength], encoder.cpp:358; WriteDistance, encoder.cpp:135-141)
+    const uint32_t l = (((tok >> 16) & 0x1FF) - 3u) & 0xFFu;             // 0..255 (masked: a literal's word holds no length)
+    const bool is258 = l == 255u;
+    uint32_t eb = 29u - (uint32_t)__builtin_clz(l | 4u);                 // 0 for l < 8
+    uint32_t sym = 257u + 4u * eb + (l >> eb);
+    uint32_t ev = l & ((1u << eb) - 1u);
+    sym = is258 ? 285u : sym; eb = is258 ? 0u : eb; ev = is258 ? 0u : ev;
+    const uint32_t hi = sym >= 280u ? 1u : 0u;                           // 256..279 -> 7 bits, 280..287 -> 8 bits 11000000+
+    const uint32_t snb = 7u + hi;
+    const uint32_t sbits = __builtin_bitreverse32(sym - 256u + (hi ? 168u : 0u)) >> (32 - snb);
+    const uint32_t ll = snb + eb;
+    const uint32_t d = ((tok & 0xFFFF) - 1u) & 0x7FFFu;                  // 0..32767 (masked likewise)
+    const uint32_t k = 31u - (uint32_t)__builtin_clz(d | 2u);
+    const uint32_t deb = k - 1u;                                         // 0 for d < 4
+    const uint32_t bucket = d < 2u ? d : 2u * k + ((d >> deb) & 1u);
+    const uint32_t dev = d & ((1u << deb) - 1u);
+    const uint32_t mbits = sbits | (ev << snb) | ((__builtin_bitreverse32(bucket) >> 27) << ll) | (dev << (ll + 5u));
+    const uint32_t mnb = ll + 5u + deb;
+    const bool ism = (tok & ZZ_TOK_MATCH) != 0;
+    bits = ism ? mbits : lbits;
+    nb = ism ? mnb : lnb;
+    if (tok == 0) { bits = 0; nb = 0; }
+}
 __device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lcodes, uint32_t tok)
 {
-    uint32_t bits = 0, nb = 0;
-    if (tok & ZZ_TOK_MATCH) {
-        const uint32_t tlen = (tok >> 16) & 0x1FF, tdist = tok & 0xFFFF;
-        const uint32_t lc = lcodes ? lcodes[tlen - 3] : fixed_lcode_packed(tlen);   // lcodes_f[matchLength], encoder.cpp:358
-        const uint32_t ll = lc >> 16;
-        uint32_t bucket, eb, ev;
-        dist_symbol(tdist, bucket, eb, ev);                              // WriteDistance, encoder.cpp:135-141
-        bits = (lc & 0xFFFF) | (bitrev(bucket, 5) << ll) | (ev << (ll + 5));
-        nb = ll + 5 + eb;
-    } else if (tok & ZZ_TOK_LIT) {
-        fixed_code(tok & 0xFF, bits, nb);                                // codes_f[*sourcePtr], encoder.cpp:367
-    }
+    (void)lcodes;
+    uint32_t bits, nb;
+    l1_token_bits(tok, bits, nb);
     ring_append(ring, bits, nb);
 }
 
@@ -639,12 +663,10 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P, zz_st
 {
     __shared__ uint32_t T[ZZ_HASH_SIZE];          // absolute position + 1, 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
-    __shared__ uint32_t lcodes[ZZ_MAX_LEN - 2];
     const int lane = lane_id();
     {
         uint4* t4 = (uint4*)T;
         for (int i = lane; i < (int)(sizeof(T) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
-        for (int l = lane; l < ZZ_MAX_LEN - 2; l += ZZ_WAVE) lcodes[l] = fixed_lcode_packed(l + 3);
     }
     bitring ring;
     ring_init(ring, ring_words, P.slots);
@@ -680,7 +702,7 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l1(zz_packet_params P, zz_st
             truncated = true;
             break;
         }
-        l1_encode_body<true, uint32_t>(P, T, lcodes, ring, P.src, P.src + P.n, (uint32_t)(done + (uint64_t)nb), nullptr, (uint32_t)done);
+        l1_encode_body<true, uint32_t>(P, T, nullptr, ring, P.src, P.src + P.n, (uint32_t)(done + (uint64_t)nb), nullptr, (uint32_t)done);
         ring_append_uniform(ring, 0, 7);                                // codes_f[256], encoder.cpp:371
         done += (uint64_t)nb;
     }
