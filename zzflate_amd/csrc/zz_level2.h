@@ -569,16 +569,20 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         if (BIAS && q + 1 + BIAS - old >= 32768u) old = 0;            // :392 (inside a cold packet every candidate is in reach)
         // the table candidate's bytes are requested at once (a lane whose candidate turns out to sit in this very
         // block takes that lane's registers instead): 16 at the candidate (:399), 8 in front of it (:92-102)
+        // Every lane loads, from a clamped address where it has nothing to load (the result is not looked at): a lane
+        // mask around a load costs three scalar instructions, and the CU's one scalar unit is what this kernel is short of.
         uint64_t ca = 0, ca2 = 0, cpre = 0;
-        if (doProbe && ins && old != 0 && q < batchEnd) {
-            ld128<SAFE>(src + (int32_t)(old - 1 - BIAS), end, ca, ca2);
-            if ((int64_t)before + (int32_t)(old - 1 - BIAS) >= 8) cpre = load64(src + (int64_t)(int32_t)(old - 1 - BIAS) - 8);
+        if (doProbe) {
+            const int32_t c0 = old ? (int32_t)(old - 1 - BIAS) : 0;
+            ld128<SAFE>(src + c0, end, ca, ca2);
+            cpre = load64(src + ((int64_t)before + c0 >= 8 ? (int64_t)c0 - 8 : 0));
         }
         // next block's own bytes: in flight during the rest of this block
-        uint64_t wan = 0, wan2 = 0, wbn = 0;
-        if (q + 64 < n) {
-            ld128<SAFE>(src + q + 64, end, wan, wan2);
-            wbn = load64(src + q + 56);
+        uint64_t wan, wan2, wbn;
+        {
+            const uint32_t qn = q + 64 < n ? q + 64 : n - 1;
+            ld128<SAFE>(src + qn, end, wan, wan2);
+            wbn = load64(src + (qn >= 8 ? qn - 8 : 0));
         }
         if (base) l2_block_barrier();     // releases the previous block's matches to the helper (the table read above had to land anyway)
         ZZ_WAVE_SYNC();
@@ -614,18 +618,19 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 const uint64_t sp = ((uint64_t)(uint32_t)__shfl((int)(wb >> 32), sl) << 32) | (uint32_t)__shfl((int)wb, sl);
                 if (inlane >= 0) { ca = sa; ca2 = sa2; cpre = sp; }
             }
-            uint32_t fwd8 = 0, bwd8 = 0, room = 0;
-            if (has) {
-                const uint64_t x = wa ^ ca, x2 = wa2 ^ ca2;            // 16 bytes at the probe and at the candidate (:399)
+            // (selects rather than branches, for the same reason; only the first eight bytes of a stream take the loop)
+            uint32_t fwd8, bwd8, room;
+            {
                 const uint64_t cb = (uint64_t)((int64_t)before + c);   // bytes in front of the candidate
                 room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
-                if (room >= 8) {
-                    const uint64_t y = wb ^ cpre;
-                    bwd8 = y ? (uint32_t)__builtin_clzll(y) >> 3 : 8;
-                } else {
+                const uint64_t y = wb ^ cpre;
+                bwd8 = (y ? (uint32_t)__builtin_clzll(y) : 64u) >> 3;
+                if (has && room < 8) {
+                    bwd8 = 0;
                     while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
                 }
-                fwd8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : (x2 ? 8 + ((uint32_t)__builtin_ctzll(x2) >> 3) : 16);   // 16 = "16 or more"
+                fwd8 = equal_bytes16(wa ^ ca, wa2 ^ ca2);              // 16 bytes at the probe and at the candidate (:399); 16 = "16 or more"
+                if (!has) { fwd8 = 0; bwd8 = 0; room = 0; }
             }
             const uint32_t broom = bwd8 < room ? bwd8 : room;
             ZZ_DRAIN();
