@@ -26,6 +26,9 @@ def h(b):
     return [len(b), hashlib.sha256(b).hexdigest()]
 
 
+h_ = h
+
+
 def inflates(b, d, fmt):
     try:
         return zlib.decompressobj(WBITS[fmt]).decompress(b) == d
@@ -131,3 +134,46 @@ def test_synthetic_tight_destinations(oracle, kind):
             else:
                 with pytest.raises(zz.ZzFlateError):
                     zz.ZzFlateEncode(d, zz.Config(zz.Format.Deflate, 1, False), dest_capacity=cap)
+
+
+def test_stream_level2_batch_start_inside_the_last_records_of_a_block(oracle):
+    """Regression (found by tools/fuzz_gpu.py, present since round 1): at levels 2,3 the sequential stream's token pass
+    works one position at a time once fewer than 64 records remain before the 20,000-record cut (so that nothing behind
+    the cut enters the hash table); when a new 16,384-byte batch began inside that stretch, the batch's second byte was
+    entered into the table by the "what the last match covers" sweep instead of being probed (encoder.cpp:383: j starts
+    at startPos + 1). The input below has such a batch start 326 bytes before the end of its second block."""
+    import torch
+    d = zlib.decompress(open(os.path.join(GOLDEN, "cases", "stream_l2_batch_start_near_record_cut.bin.z"), "rb").read())
+    ctx = zz.Context(0)
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = 2 * len(d) + 1024
+    dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    for lvl in (2, 3):
+        w = ctx.encode_stream(src, len(d), dst, cap, zz.Format.Deflate, lvl)
+        assert dst[:w].cpu().numpy().tobytes() == oracle.encode(d, 2, lvl), lvl
+
+
+def test_stream_level2_one_position_at_a_time_everywhere(oracle, corpus, tmp_path):
+    """The same code path, everywhere: a build with -DZZ_ST_ALWAYS_CAREFUL takes the one-position-at-a-time form of the
+    token pass for whole streams; it must still be the reference's stream."""
+    import ctypes
+    import subprocess
+    import torch
+    lib = str(tmp_path / "libzz_careful.so")
+    csrc = os.path.join(os.path.dirname(zz.__file__), "csrc")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZZ_ST_ALWAYS_CAREFUL",
+                    "-o", lib, os.path.join(csrc, "zz_api.hip"), os.path.join(csrc, "zz_cxx_shim.cpp")], check=True)
+    L = ctypes.CDLL(lib)
+    u64, vp, ci = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int
+    h = vp()
+    assert L.zz_ctx_create(0, ctypes.byref(h)) == 0
+    for fname in ("alice29.txt", "kennedy.xls", "ptt5", "lcet10.txt"):
+        d = corpus[fname]
+        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        cap = 2 * len(d) + 1024
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        out = u64(0)
+        rc = L.zz_encode_stream_device(h, vp(src.data_ptr()), u64(len(d)), vp(dst.data_ptr()), u64(cap), ctypes.byref(out), ci(0), ci(2), vp(0))
+        assert rc == 0
+        assert h_(dst[:out.value].cpu().numpy().tobytes()) == G["files"][fname]["whole"]["0"]["2"], fname
+    L.zz_ctx_destroy(h)

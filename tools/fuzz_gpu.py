@@ -50,6 +50,9 @@ for it in range(cases):
             if (ok_ref and got != want) or (not ok_ref and got is not None and lvl == 1):
                 bad += 1
                 print("MISMATCH stream", it, kind, len(d), cap, lvl, fmt, got is None, flush=True)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                open(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{it}.in"), "wb").write(d)
+                open(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{it}.got"), "wb").write(got or b"")
         else:
             want, sizes = o.encode_callback(d, fmt, lvl)
             cap = 2 * len(d) + 4096

@@ -100,10 +100,15 @@ __device__ __forceinline__ uint32_t st_token_pass(st_state& S, uint32_t byteCoun
         uint32_t nextProbe = bstart + 1;                                  // j (:383); the batch's first byte is never probed
         uint32_t ins_end = bstart + 1;                                    // positions of this batch below ins_end are in the table
         bool cut = false;                                                 // the record array filled up (:426-430)
+        bool matched = false;       // this batch has seen a match: B is the end of one, not the batch's initial bstart + 1
         while (!cut) {
             // near the record limit chunks are one position wide, so that nothing past the cut is ever inserted
+#ifdef ZZ_ST_ALWAYS_CAREFUL
+            const bool careful = true;
+#else
             const bool careful = nrec + 64 >= ZZ_ST_MAX_RECORDS;
-            if (careful && B >= ins_end) {
+#endif
+            if (careful && matched && B >= ins_end) {
                 // AddHashEntries (:418): everything the last match covers, up to and including backRefEnd
                 for (uint32_t sb = ins_end; sb <= B; sb += 64) {
                     uint32_t h2;
@@ -173,13 +178,14 @@ __device__ __forceinline__ uint32_t st_token_pass(st_state& S, uint32_t byteCoun
                     nrec++;
                     B = ms + mlen;                                        // :422
                     nextProbe = B + 1;                                    // :424
+                    matched = true;
                     if (nrec == ZZ_ST_MAX_RECORDS) { cut = true; break; } // :426-430
                     if (nextProbe >= hi) break;
                 }
             }
         }
         // what the last match covers beyond the inserted range (an overrun past the batch end, or the cut)
-        if (B >= ins_end) {
+        if (matched && B >= ins_end) {
             for (uint32_t sb = ins_end; sb <= B; sb += 64) {
                 uint32_t h2;
                 (void)st_insert_chunk(S, sb, sb, (B + 1 < sb + 64 ? B + 1 : sb + 64), h2);
