@@ -45,6 +45,7 @@ namespace zz {
 #define ZZ_L2_WIN 16                                // bitmap window, words of 64 positions (11 are live at a time)
 #define ZZ_L2_LAG 5                                 // a block is final once the probe front is 5 blocks ahead
 #define ZZ_L2_HIST_WORDS 160                        // 286 lit/len + 30 distance counters, two per word
+#define ZZ_L2_LDS_BYTES (16384 + 560 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)   // (+ 16: the slot non-inserting lanes use)
 
 __device__ __forceinline__ uint32_t mbcnt(uint64_t m)   // set bits of m below this lane
 {
@@ -564,8 +565,12 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         const bool ins = q < n && q != skipPos && q != 0;
         const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
         const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
-        uint32_t old = 0;
-        if (ins) { old = T[h]; T[h] = (uint16_t)(q + 1 + BIAS); }     // :389-390 / :474-480
+        // lanes that must not insert (past the end, byte 0, a batch's first byte) read and write a slot of their own behind
+        // the kernel's other LDS data instead: no lane mask, i.e. no scalar instructions, around the table accesses
+        const uint32_t hs = ins ? h : (uint32_t)(ZZ_L2_LDS_BYTES / 2);
+        uint32_t old = T[hs];                                         // :389
+        T[hs] = (uint16_t)(q + 1 + BIAS);                             // :390 / :474-480
+        if (!ins) old = 0;
         if (BIAS && q + 1 + BIAS - old >= 32768u) old = 0;            // :392 (inside a cold packet every candidate is in reach)
         // the table candidate's bytes are requested at once (a lane whose candidate turns out to sit in this very
         // block takes that lane's registers instead): 16 at the candidate (:399), 8 in front of it (:92-102)
@@ -590,8 +595,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         // lane for every member of a set and a different one for different sets -- a 6-bit key. Six ballots give
         // every lane the mask of its set (no loop over sets); the candidate of a later member is the nearest
         // earlier member, and the table must end up holding the last member.
-        uint32_t rb = 0;
-        if (ins) rb = T[h];
+        const uint32_t rb = T[hs];
         uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
         int inlane = -1;                                              // >= 0: the candidate is that lane of this block
         if (ballot(ins && rb != q + 1 + BIAS)) {
@@ -932,7 +936,6 @@ struct zz_l2_params {
     uint32_t* work;        // packets handed out beyond the first gridDim.x (zero at launch)
 };
 
-#define ZZ_L2_LDS_BYTES (16384 + 560 + 2 * ZZ_L2_WIN * 8 + ZZ_L2_HIST_WORDS * 4)
 #define ZZ_L2_THREADS (2 * ZZ_WAVE)
 // one wave's own memory traffic has landed (the code after the token pass runs on wavefront 0 alone: no s_barrier there)
 #define ZZ_WAVE_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
     // The hash table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the
     // code tables all live inside it; the bit ring (used after the token pass) shares its space with the
     // hand-over slots (used during it); the bitmap window and the packed counters have their own.
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES + 16];
     uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table during the token pass
     uint32_t* symF = (uint32_t*)(lds + 8192);                     // 1280: 286 lit/len + pad | 30 dist at [288..318)
     uint32_t* distF = symF + 288;
