@@ -84,6 +84,36 @@ __device__ __forceinline__ uint32_t equal_bytes16(uint64_t x, uint64_t x2)
     const uint32_t c2 = x2 ? (uint32_t)__builtin_ctzll(x2) : 64u;
     return (c1 < 64u ? c1 : 64u + c2) >> 3;
 }
+// the same in bits, for callers that cap the count themselves: min(cap, 8 x the number of equal leading bytes), and cap if
+// all 16 bytes are equal. Ten instructions: v_ffbl_b32 gives -1 for 0, the additions saturate, the minima pick. (Inline
+// asm, because the compiler knows that ctz + 32 cannot overflow and turns the saturating additions back into compares
+// and selects, each with its wait states.)
+__device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t v)
+{
+    uint32_t r;
+    asm("v_ffbl_b32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+template <int K> __device__ __forceinline__ uint32_t add_sat_k(uint32_t v)
+{
+    uint32_t r;
+    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t equal_bits128(uint64_t x, uint64_t x2, uint32_t cap)
+{
+    const uint32_t f0 = ffbl_or_ones((uint32_t)x), f1 = add_sat_k<32>(ffbl_or_ones((uint32_t)(x >> 32)));
+    const uint32_t f2 = ffbl_or_ones((uint32_t)x2), f3 = add_sat_k<32>(ffbl_or_ones((uint32_t)(x2 >> 32)));
+    const uint32_t hi = add_sat_k<64>(f2 < f3 ? f2 : f3);
+    const uint32_t lo = umin3(f0, f1, cap);
+    return lo < hi ? lo : hi;
+}
 __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encoder.cpp:11-17
 {
     return ((three_bytes & 0xFFFFFFu) * 0x00d68664u) >> (32 - ZZ_HASH_BITS);
@@ -275,6 +305,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                                                uint32_t* tokbuf = nullptr, uint32_t start = 0)
 {
     const int lane = lane_id();
+    const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
     ZZ_PROF_DECL
     uint32_t grp = 0;
     uint32_t cur = start;
@@ -306,7 +337,10 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         const uint32_t old = ((sizeof(TT) == 4 || BIAS) && p + 1 + BIAS - oldraw > 0x8000u) ? 0 : oldraw;
         // every lane loads (lanes without a candidate: the packet's first bytes, result unused) -- no lane mask to set up
         uint64_t wc, wc2;
-        ld128<SAFE>(src + (old ? (int32_t)(old - 1 - BIAS) : (int32_t)start), end, wc, wc2);  // encoder.cpp:350
+        if (SPLIT && BIAS == 0)   // (a saturating subtraction and an unsigned offset from the uniform base: two instructions)
+            ld128<SAFE>(src + __builtin_elementwise_sub_sat(old, 1u), end, wc, wc2);
+        else
+            ld128<SAFE>(src + (old ? (int32_t)(old - 1 - BIAS) : (int32_t)start), end, wc, wc2);  // encoder.cpp:350
         if (SPLIT && cur != start) l1_group_barrier();                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
@@ -322,55 +356,51 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // hashes, a different one for different sets -- a 6-bit key, where the hash has 13 bits. Six ballots give
         // every lane the mask of its set, whatever the number of sets (no loop over them).
         const uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1 + BIAS));
-        uint64_t multimask = 0;    // lanes whose hash occurs more than once in this group
-        uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (0 if unique)
+        uint64_t multimask = 0;    // lanes that have an earlier lane of the group with their hash
+        uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (itself included)
         uint32_t info = 0;
         if (lostmask) {
             uint32_t W = (uint32_t)lane;
             if (active) W = (rb - 1u - BIAS - cur) & 63u;
-            const uint64_t set = wave_match6(W);
-            const bool multi = (set & (set - 1)) != 0;
-            multimask = ballot(multi);
-            if (multi) {
-                myset = set;
-                const uint64_t below = set & ((1ull << lane) - 1);        // earlier lanes with my hash
-                if (below) {
-                    info = ZZ_WI_DUP | ((uint32_t)(63 - __builtin_clzll(below)) << ZZ_WI_QLANE_SHIFT);
-                    if (__builtin_popcountll(set) > 2) info |= ZZ_WI_HARD;   // ... shared by more than two lanes
-                }
-            }
+            myset = wave_match6(W);
+            // (selects, not a lane-mask region: a lane alone with its hash has nothing below it and ends up with info = 0)
+            const uint64_t below = myset & below_me;                      // earlier lanes with my hash
+            const uint32_t ql = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+            const uint32_t dup = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | (__builtin_popcountll(myset) > 2 ? ZZ_WI_HARD : 0u);   // ... shared by more than two lanes
+            multimask = ballot(below != 0);
+            info = (below != 0 && active) ? dup : 0u;                     // (a lane past the end may sit in a set: never an event)
         }
         ZZ_T(3);
         ZZ_DRAIN();
         ZZ_T(4);
         // (2) lengths against both possible candidates, capped at 16 ("16 or more")
         const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
-        const uint32_t capn = left < ZZ_WI_CAP ? left : ZZ_WI_CAP;
+        // cap17: 8 x min(bytes left, 17) -- a length of 17 says "all 16 compared bytes are equal and more remain"
+        const uint32_t cap17 = (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;   // (0 for lanes past the end)
         const uint64_t x = w ^ wc;                                      // (only looked at where there is a candidate)
-        uint32_t la = equal_bytes16(x, w2 ^ wc2);
-        if (la > capn) la = capn;
-        if (!(active && old)) la = 0;
-        info |= la;
-        if (la == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTA;
+        uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
+        if (!old) la = 0;
+        info |= la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la;
         if (multimask) {
             // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
             const int ql = (info & ZZ_WI_DUP) ? (int)ZZ_WI_QLANE(info) : lane;
             const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), ql) << 32) | (uint32_t)__shfl((int)w, ql);
             const uint64_t wq2 = ((uint64_t)(uint32_t)__shfl((int)(w2 >> 32), ql) << 32) | (uint32_t)__shfl((int)w2, ql);
-            uint32_t lb = equal_bytes16(w ^ wq, w2 ^ wq2);
-            if (lb > capn) lb = capn;
+            uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
             if (!(info & ZZ_WI_DUP)) lb = 0;
-            info |= lb << ZZ_WI_LENB_SHIFT;
-            if (lb == ZZ_WI_CAP && left > ZZ_WI_CAP) info |= ZZ_WI_EXTB;
+            info |= lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT);
         }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
-        const uint64_t E = ballot(active && ((info & ZZ_WI_HARD) || ZZ_WI_LENA(info) >= 4 || ZZ_WI_LENB(info) >= 4));
+        // (HARD, or lenA >= 4, or lenB >= 4; one compare, because a ballot of anything else costs two more instructions)
+        // (lanes past the end have info = 0: no lengths because nothing is left, no flags by the line above)
+        const uint64_t E = ballot((info & (ZZ_WI_HARD | 0x1Cu | (0x1Cu << ZZ_WI_LENB_SHIFT))) != 0);
         // a plain match knows where the walk continues: the first event at or after its end (0 = none). With that
         // in the info word the scalar loop hops from match to match without re-scanning the event mask.
         {
-            const uint32_t endl = (uint32_t)lane + la;
-            const uint64_t m = endl >= 64 ? 0 : (E & (~0ull << endl));
-            info |= (m ? (uint32_t)__builtin_ctzll(m) : 0u) << ZZ_WI_NEXT_SHIFT;
+            const uint32_t endl = (uint32_t)lane + la;                  // (la = 17 on EXTA lanes, whose NEXT nobody reads)
+            const uint64_t m = E >> (endl & 63u);                       // (endl >= 64: whatever this finds lies at 64 or beyond)
+            const uint32_t nx = endl + (m ? (uint32_t)__builtin_ctzll(m) : 64u);
+            info |= ((nx < 64u ? nx : 64u) & 63u) << ZZ_WI_NEXT_SHIFT;   // (64 & 63 = 0 = none: no compare-and-select)
         }
 
         ZZ_T(5); ZZ_C(10, 1);
@@ -378,7 +408,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip), so runs
         // of "simple" matches go through a hand-written 12-instruction loop; everything else drops out to C++.
         uint64_t mst = 0, cov = 0, usedB = 0;    // match-start lanes / lanes covered by matches / matched the in-group candidate
-        uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events
+        uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events (length | 0x8000) ...
+        uint64_t ovmL = 0, ovmC = 0;             // ... and the lanes that hold one
         uint32_t pos = 0;
         for (;;) {
             l1_fast_walk(E, info, nact, pos, mst, cov, usedB);
@@ -398,7 +429,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                     if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
                         const int32_t cand = useB ? (int32_t)(cur + ZZ_WI_QLANE(inf)) : (int32_t)(readlane(old, e) - 1 - BIAS);
                         mlen = wave_extend_match<SAFE>(src, pe, cand, maxlen, end, ZZ_WI_CAP);
-                        if (lane == e) ovlen = mlen;
+                        if (lane == e) ovlen = mlen | 0x8000u;
+                        ovmL |= 1ull << e;
                     }
                     if (useB) usedB |= 1ull << e;
                 }
@@ -421,7 +453,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                     else mlen = wave_extend_match<SAFE>(src, pe, (int32_t)(cand1 - 1 - BIAS), maxlen, end);
                     if (mlen > maxlen) mlen = maxlen;
                 }
-                if (lane == e) { ovlen = mlen; ovcand1 = cand1; }
+                if (lane == e) { ovlen = mlen | 0x8000u; ovcand1 = cand1; }
+                ovmL |= 1ull << e; ovmC |= 1ull << e;
             }
             if (mlen > 3) {                                              // encoder.cpp:356
                 mst |= 1ull << e;
@@ -435,7 +468,14 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_T(6);
         // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
         // (the walk leaves 1 <= pos, and pos <= nact wherever nact < 64: every lane below pos is an active one)
-        const uint64_t committed = (~cov & (~0ull >> (64u - (pos < 64u ? pos : 64u)))) | mst;
+        uint64_t committed;
+        if (SPLIT) {    // five scalar instructions (left to itself the compiler does this 64-bit arithmetic on the VALU)
+            uint32_t t;
+            asm("s_min_u32 %1, %2, 64\n\ts_sub_u32 %1, 64, %1\n\ts_lshr_b64 %0, -1, %1\n\ts_andn2_b64 %0, %0, %3\n\ts_or_b64 %0, %0, %4"
+                : "=&s"(committed), "=&s"(t) : "s"(pos), "s"(cov), "s"(mst) : "scc");
+        } else {
+            committed = (~cov & (~0ull >> (64u - (pos < 64u ? pos : 64u)))) | mst;
+        }
         const uint32_t next = cur + pos;
         // next group's bytes: in flight while this group is repaired
         uint64_t wnext = 0, wnext2 = 0;
@@ -446,22 +486,35 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // highest position wins -- the state the serial loop leaves behind
         const bool is_committed = (committed >> lane) & 1;
         ZZ_WAVE_SYNC();
-        if (tact && !is_committed) T[h] = (TT)oldraw;
+        if (SPLIT) {    // the scalar mask is the lane mask of the store: no compare, no branch
+            uint64_t saved;
+            asm volatile("s_andn1_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                         : "=&s"(saved) : "s"(committed), "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) TT*)(T + h)), "v"(oldraw)
+                         : "memory", "scc");
+        } else if (tact && !is_committed) T[h] = (TT)oldraw;
         if (multimask) {
             ZZ_WAVE_SYNC();
-            const bool winner = is_committed && myset && (((myset & committed) >> lane) >> 1) == 0;
+            const bool winner = is_committed && (myset & committed & above_me) == 0;
             if (winner) T[h] = (TT)(p + 1 + BIAS);
         }
         ZZ_WAVE_SYNC();
 
         // (5) this group's tokens, emitted by the next iteration
-        {   // (masks, not branches: the values are cheap and a lane-mask region is three scalar instructions)
+        if (SPLIT) {
+            // the walk's scalar masks are the lane predicates of the selects (sel_lanes): no shifting by the lane id
+            const uint32_t la_ = ZZ_WI_LENA(info) | 0x8000u, lb_ = ZZ_WI_LENB(info) | 0x8000u;   // ZZ_TOK_MATCH >> 16 rides along
+            const uint32_t tl = sel_lanes(ovmL, ovlen, sel_lanes(usedB, lb_, la_));
+            const uint32_t cn = sel_lanes(ovmC, ovcand1, sel_lanes(usedB, cur + ZZ_WI_QLANE(info) + 1 + BIAS, old));
+            const uint32_t tmatch = (tl << 16) | (p + 1 + BIAS - cn);
+            const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
+            ptok = keep_lanes(committed, sel_lanes(mst, tmatch, tlit));
+        } else {   // (masks, not branches: the values are cheap and a lane-mask region is three scalar instructions)
             const uint32_t mB = 0u - (uint32_t)((usedB >> lane) & 1);          // all ones where the in-group candidate matched
             const uint32_t la_ = ZZ_WI_LENA(info), ca_ = old;
             const uint32_t tl = la_ ^ ((la_ ^ ZZ_WI_LENB(info)) & mB);
             const uint32_t cn = ca_ ^ ((ca_ ^ (cur + ZZ_WI_QLANE(info) + 1 + BIAS)) & mB);
-            const uint32_t mL = 0u - (uint32_t)(ovlen != 0), mC = 0u - (uint32_t)(ovcand1 != 0);
-            const uint32_t tlen = tl ^ ((tl ^ ovlen) & mL);
+            const uint32_t mL = 0u - (uint32_t)((ovmL >> lane) & 1), mC = 0u - (uint32_t)((ovmC >> lane) & 1);
+            const uint32_t tlen = tl ^ ((tl ^ (ovlen & 0x1FFu)) & mL);
             const uint32_t cand1 = cn ^ ((cn ^ ovcand1) & mC);
             const uint32_t tmatch = ZZ_TOK_MATCH | (tlen << 16) | (p + 1 + BIAS - cand1);
             const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);

@@ -16,7 +16,7 @@ namespace zz {
         __builtin_amdgcn_wave_barrier();                            \
     } while (0)
 
-__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ uint32_t readlane(uint32_t v, int l)
@@ -63,19 +63,47 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t x)
 }
 
 // Lanes holding the same 6-bit key as this lane (keys are lane ids, so six ballots decide it for all lanes at once).
-// Per bit: the ballot, "my bit as a mask" (bfe on the complemented key) and one v_bitop3 per half: (ballot ^ ~mybit) & set.
+// Per bit four instructions: "my bit as a mask" (v_bfe_i32), the ballot of that mask, and one v_bitop3 per half:
+// ~(ballot ^ mybit) & set. The six ballots are issued back to back into six SGPR pairs: a VALU instruction that reads an
+// SGPR the VALU wrote needs two wait states on gfx950, and ballot-then-use per bit would spend them on s_nops.
 __device__ __forceinline__ uint64_t wave_match6(uint32_t key)
 {
-    const uint32_t nkey = ~key;
-    uint32_t lo = ~0u, hi = ~0u;
-#pragma unroll
-    for (int kb = 0; kb < 6; ++kb) {
-        const uint64_t bm = __ballot((key >> kb) & 1);
-        const uint32_t nm = (uint32_t)(((int32_t)(nkey << (31 - kb))) >> 31);   // all ones where my bit is clear
-        lo = __builtin_amdgcn_bitop3_b32((uint32_t)bm, nm, lo, 0x28);          // (a ^ b) & c
-        hi = __builtin_amdgcn_bitop3_b32((uint32_t)(bm >> 32), nm, hi, 0x28);
-    }
+    uint32_t m0, m1, m2, m3, m4, m5;
+    uint64_t b0, b1, b2, b3, b4, b5;
+    asm("v_bfe_i32 %0, %12, 0, 1\n\tv_bfe_i32 %1, %12, 1, 1\n\tv_bfe_i32 %2, %12, 2, 1\n\t"
+        "v_bfe_i32 %3, %12, 3, 1\n\tv_bfe_i32 %4, %12, 4, 1\n\tv_bfe_i32 %5, %12, 5, 1\n\t"
+        "v_cmp_ne_u32_e64 %6, 0, %0\n\tv_cmp_ne_u32_e64 %7, 0, %1\n\tv_cmp_ne_u32_e64 %8, 0, %2\n\t"
+        "v_cmp_ne_u32_e64 %9, 0, %3\n\tv_cmp_ne_u32_e64 %10, 0, %4\n\tv_cmp_ne_u32_e64 %11, 0, %5\n\t"
+        "s_nop 1"                                                              // (the compiler's next instruction may read %11)
+        : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4), "=&v"(m5),
+          "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3), "=&s"(b4), "=&s"(b5)
+        : "v"(key));
+    uint32_t lo, hi;
+    lo = __builtin_amdgcn_bitop3_b32((uint32_t)b0, m0, ~0u, 0x82);             // ~(a ^ b) & c
+    hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b0 >> 32), m0, ~0u, 0x82);
+    lo = __builtin_amdgcn_bitop3_b32((uint32_t)b1, m1, lo, 0x82); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b1 >> 32), m1, hi, 0x82);
+    lo = __builtin_amdgcn_bitop3_b32((uint32_t)b2, m2, lo, 0x82); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b2 >> 32), m2, hi, 0x82);
+    lo = __builtin_amdgcn_bitop3_b32((uint32_t)b3, m3, lo, 0x82); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b3 >> 32), m3, hi, 0x82);
+    lo = __builtin_amdgcn_bitop3_b32((uint32_t)b4, m4, lo, 0x82); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b4 >> 32), m4, hi, 0x82);
+    lo = __builtin_amdgcn_bitop3_b32((uint32_t)b5, m5, lo, 0x82); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b5 >> 32), m5, hi, 0x82);
     return ((uint64_t)hi << 32) | lo;
+}
+
+// A 64-bit scalar mask used directly as the lane predicate of a select (lane l takes `a` where bit l is set): one
+// v_cndmask, where the compiler would shift the mask by the lane id and test a bit (three or four instructions).
+// `m` must have been written by SCALAR instructions (inline-asm "=s" outputs, or uniform integer arithmetic): an SGPR
+// written by the VALU needs two wait states before a VALU instruction reads it, and the compiler cannot see into the asm.
+__device__ __forceinline__ uint32_t sel_lanes(uint64_t m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t keep_lanes(uint64_t m, uint32_t a)      // a where the bit is set, else 0
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
+    return r;
 }
 
 // ---- loads ------------------------------------------------------------------------------------
