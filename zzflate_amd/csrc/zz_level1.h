@@ -236,6 +236,7 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
 // a committed token as it waits one iteration for emission: bit31 match (len<<16 | dist), bit30 literal (byte)
 #define ZZ_TOK_MATCH 0x80000000u
 #define ZZ_TOK_LIT 0x40000000u
+#define ZZ_TOK_LAST 0x20000000u   // (packet mode, every lane's word) this was the packet's last group
 
 // Fixed-Huffman fragment of one token, by arithmetic and selects only (RFC 1951 3.2.5/3.2.6; the reference's tables
 // lcodes_f / dcodes_f / codes_f, fixedhuffmanluts.cpp:5-55, hold the same values): no lane-mask region, i.e. no scalar
@@ -287,7 +288,9 @@ __device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lc
 // The emitter's work per group is a fifth of the parser's, so it is always the one waiting (asleep in the barrier,
 // not polling: a polling emitter with an LDS queue was measured 6 % slower) and the parser never stalls.
 // `tokbuf` is the buffer; `ring` and `lcodes` are not touched.
-#define ZZ_L1_TOKSLOT 65u      // 64 tokens + "this was the last group"
+#define ZZ_L1_TOKSLOT 64u      // 64 tokens; two slots, 512 bytes, 512-byte aligned: slot = byte address ^ 0x100
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ lds_u32* lds_flip_slot(lds_u32* p) { return (lds_u32*)(size_t)((uint32_t)(size_t)p ^ 0x100u); }
 __device__ __forceinline__ void l1_group_barrier()
 {
     // the LDS traffic of this wave must have landed; global loads (the next group's prefetch) stay in flight
@@ -307,7 +310,6 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
     const int lane = lane_id();
     const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
     ZZ_PROF_DECL
-    uint32_t grp = 0;
     uint32_t cur = start;
     uint32_t ptok = 0;                                                    // previous group's tokens
     // Packet mode (SPLIT): lanes past the block's end take part in the table accesses and loads like everyone else --
@@ -319,10 +321,15 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
     uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position
     if (MASKED) { if (start + (uint32_t)lane < n) ld128<SAFE>(src + start + lane, end, w, w2); }
     else ld128<SAFE>(src + (start + (uint32_t)lane < n ? start + (uint32_t)lane : n - 1), end, w, w2);
-    while (cur < n) {
-        const uint32_t nact = (n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE;
+    lds_u32* slot = SPLIT ? (lds_u32*)tokbuf + lane : nullptr;            // this lane's word of the hand-over slot in use
+    // One group of 64 positions. INTERIOR: every lane holds a position with at least 17 bytes after it (all lanes active,
+    // no length can run into the block's end) -- all but the last two groups of a packet; the lane-activity compares,
+    // the clamps and their scalar bookkeeping drop out of that copy of the code.
+    auto group = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        const uint32_t nact = INTERIOR ? ZZ_WAVE : ((n - cur) < ZZ_WAVE ? (n - cur) : ZZ_WAVE);
         const uint32_t p = cur + lane;
-        const bool active = lane < (int)nact;
+        const bool active = INTERIOR ? true : lane < (int)nact;
         const bool tact = MASKED ? active : true;                       // takes part in table accesses
 
         ZZ_T(0);
@@ -341,7 +348,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             ld128<SAFE>(src + __builtin_elementwise_sub_sat(old, 1u), end, wc, wc2);
         else
             ld128<SAFE>(src + (old ? (int32_t)(old - 1 - BIAS) : (int32_t)start), end, wc, wc2);  // encoder.cpp:350
-        if (SPLIT && cur != start) l1_group_barrier();                  // second half of the previous group's hand-over
+        if (SPLIT) l1_group_barrier();                                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
         if (tact) rb = T[h];                                            // the slot holds whichever lane wrote last
@@ -356,40 +363,36 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // hashes, a different one for different sets -- a 6-bit key, where the hash has 13 bits. Six ballots give
         // every lane the mask of its set, whatever the number of sets (no loop over them).
         const uint64_t lostmask = ballot(active && rb != (uint32_t)(TT)(p + 1 + BIAS));
-        uint64_t multimask = 0;    // lanes that have an earlier lane of the group with their hash
+        // (2) lengths against both possible candidates, 16 bytes compared ("16 or more" = 17 where more bytes remain)
+        const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
+        // cap17: 8 x min(bytes left, 17)
+        const uint32_t cap17 = INTERIOR ? 8u * (ZZ_WI_CAP + 1) : (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;   // (0 for lanes past the end)
         uint64_t myset = 0;        // per lane: all lanes of the group sharing my hash (itself included)
         uint32_t info = 0;
-        if (lostmask) {
+        if (lostmask) {            // some lane's store was overwritten: at least one hash occurs twice
             uint32_t W = (uint32_t)lane;
             if (active) W = (rb - 1u - BIAS - cur) & 63u;
             myset = wave_match6(W);
             // (selects, not a lane-mask region: a lane alone with its hash has nothing below it and ends up with info = 0)
             const uint64_t below = myset & below_me;                      // earlier lanes with my hash
-            const uint32_t ql = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-            const uint32_t dup = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | (__builtin_popcountll(myset) > 2 ? ZZ_WI_HARD : 0u);   // ... shared by more than two lanes
-            multimask = ballot(below != 0);
-            info = (below != 0 && active) ? dup : 0u;                     // (a lane past the end may sit in a set: never an event)
+            const bool dup = below != 0 && active;                        // (a lane past the end may sit in a set: never an event)
+            const uint32_t ql = dup ? 63u - (uint32_t)__builtin_clzll(below | 1ull) : (uint32_t)lane;
+            // the in-group candidate's bytes come from its lane's registers, while the table candidate's are still in flight
+            // (ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part)
+            const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), (int)ql) << 32) | (uint32_t)__shfl((int)w, (int)ql);
+            const uint64_t wq2 = ((uint64_t)(uint32_t)__shfl((int)(w2 >> 32), (int)ql) << 32) | (uint32_t)__shfl((int)w2, (int)ql);
+            const uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
+            const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | ((uint32_t)__builtin_popcountll(myset) > 2u ? ZZ_WI_HARD : 0u)   // ... shared by more than two lanes
+                                | (lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT));
+            info = dup ? di : 0u;
         }
         ZZ_T(3);
         ZZ_DRAIN();
         ZZ_T(4);
-        // (2) lengths against both possible candidates, capped at 16 ("16 or more")
-        const uint32_t left = active ? n - p : 0;                       // bytes left in the block (D1 clamp)
-        // cap17: 8 x min(bytes left, 17) -- a length of 17 says "all 16 compared bytes are equal and more remain"
-        const uint32_t cap17 = (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;   // (0 for lanes past the end)
         const uint64_t x = w ^ wc;                                      // (only looked at where there is a candidate)
         uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
         if (!old) la = 0;
         info |= la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la;
-        if (multimask) {
-            // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
-            const int ql = (info & ZZ_WI_DUP) ? (int)ZZ_WI_QLANE(info) : lane;
-            const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), ql) << 32) | (uint32_t)__shfl((int)w, ql);
-            const uint64_t wq2 = ((uint64_t)(uint32_t)__shfl((int)(w2 >> 32), ql) << 32) | (uint32_t)__shfl((int)w2, ql);
-            uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
-            if (!(info & ZZ_WI_DUP)) lb = 0;
-            info |= lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT);
-        }
         // events: lanes that can start a match under some parse; "simple" ones need no look at the parse
         // (HARD, or lenA >= 4, or lenB >= 4; one compare, because a ballot of anything else costs two more instructions)
         // (lanes past the end have info = 0: no lengths because nothing is left, no flags by the line above)
@@ -492,10 +495,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
                          : "=&s"(saved) : "s"(committed), "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) TT*)(T + h)), "v"(oldraw)
                          : "memory", "scc");
         } else if (tact && !is_committed) T[h] = (TT)oldraw;
-        if (multimask) {
+        if (lostmask) {
             ZZ_WAVE_SYNC();
-            const bool winner = is_committed && (myset & committed & above_me) == 0;
-            if (winner) T[h] = (TT)(p + 1 + BIAS);
+            if (SPLIT) {
+                const uint64_t wm = ballot((myset & committed & above_me) == 0) & committed;
+                uint64_t saved;
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(wm), "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) TT*)(T + h)), "v"(p + 1 + BIAS)
+                             : "memory", "scc");
+            } else {
+                const bool winner = is_committed && (myset & committed & above_me) == 0;
+                if (winner) T[h] = (TT)(p + 1 + BIAS);
+            }
         }
         ZZ_WAVE_SYNC();
 
@@ -507,7 +518,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             const uint32_t cn = sel_lanes(ovmC, ovcand1, sel_lanes(usedB, cur + ZZ_WI_QLANE(info) + 1 + BIAS, old));
             const uint32_t tmatch = (tl << 16) | (p + 1 + BIAS - cn);
             const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
-            ptok = keep_lanes(committed, sel_lanes(mst, tmatch, tlit));
+            ptok = keep_lanes(committed, sel_lanes(mst, tmatch, tlit)) | (next >= n ? ZZ_TOK_LAST : 0u);
         } else {   // (masks, not branches: the values are cheap and a lane-mask region is three scalar instructions)
             const uint32_t mB = 0u - (uint32_t)((usedB >> lane) & 1);          // all ones where the in-group candidate matched
             const uint32_t la_ = ZZ_WI_LENA(info), ca_ = old;
@@ -525,10 +536,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         if (SPLIT) {
             // hand-over, first half: the tokens go to the slot now; the barrier that releases them to the emitter
             // sits in the next trip, behind the wait for the table read that trip needs anyway
-            uint32_t* slot = tokbuf + (grp & 1) * ZZ_L1_TOKSLOT;
-            slot[lane] = ptok;
-            slot[64] = next >= n;                   // (every lane stores the same word: no lane mask to set up)
-            grp++;
+            *slot = ptok;
+            slot = lds_flip_slot(slot);
         }
         if (sizeof(TT) == 4 && ring.flushed >= (1u << 24)) {
             // long streams: slide the ring's origin (by a multiple of the ring size, so slots keep their meaning)
@@ -540,7 +549,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         w = wnext;
         w2 = wnext2;
         ZZ_T(8);
-    }
+    };
+    if (SPLIT) while (cur + ZZ_WAVE + ZZ_WI_CAP <= n) group(std::true_type{});     // lane 63 has 17 bytes left
+    while (cur < n) group(std::false_type{});
     if (!SPLIT) l1_emit_tokens(ring, lcodes, ptok);
     else l1_group_barrier();                                            // the last group's hand-over
     ZZ_PROF_FLUSH(P);
@@ -551,14 +562,14 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
 // g + 1, which this wave reaches after the read.
 __device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf)
 {
-    const int lane = lane_id();
-    for (uint32_t grp = 0;; ++grp) {
+    const lds_u32* slot = (const lds_u32*)tokbuf + lane_id();
+    l1_group_barrier();                                                  // the parser's barrier in front of its first group
+    for (;;) {
         l1_group_barrier();
-        const uint32_t* slot = tokbuf + (grp & 1) * ZZ_L1_TOKSLOT;
-        const uint32_t tok = slot[lane];
-        const uint32_t last = uniform(slot[64]);
-        l1_emit_tokens(ring, nullptr, tok);
-        if (last) break;
+        const uint32_t tok = *slot;
+        slot = lds_flip_slot((lds_u32*)slot);
+        l1_emit_tokens(ring, nullptr, tok & ~ZZ_TOK_LAST);
+        if (uniform(tok) & ZZ_TOK_LAST) break;                           // (lane 0 of a group always holds a token)
     }
 }
 
@@ -684,10 +695,10 @@ __device__ __forceinline__ void l1_packet_emitter(const zz_packet_params& P, uin
 // access moves a 64-byte sector for two bytes.)
 __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
 {
-    // table + ring + token slots = 17,416 bytes <= 17,920 = 35 LDS granules: NINE workgroups share a CU
+    // table + ring + token slots = 17,408 bytes <= 17,920 = 35 LDS granules: NINE workgroups share a CU
     __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
-    __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
+    __shared__ __attribute__((aligned(512))) uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
     const uint32_t k = blockIdx.x;
     if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<0>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1w(zz_packet_params P
 {
     __shared__ uint16_t T[ZZ_HASH_SIZE];          // position + 1 + 32768; 0 = empty
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
-    __shared__ uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
+    __shared__ __attribute__((aligned(512))) uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
     const uint32_t k = blockIdx.x;
     if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<32768u>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
