@@ -162,75 +162,93 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 // group is done.
 // `nact`: lanes of the group that hold positions; when no event is left, pos comes back as max(pos, nact): the rest are
 // literals and the group is done (the caller need not look at E again).
+// FIRST: the group's first entry (pos = 0): the first event comes straight from E. Otherwise: re-entry behind an event
+// the C++ path decided; pos may lie at or beyond 64 (then there is nothing to do).
+template <bool FIRST>
 __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t nact, uint32_t& pos, uint64_t& mst, uint64_t& cov,
                                              uint64_t& usedB)
 {
     uint64_t tmp;
     int32_t e, e2;
     uint32_t inf, len, q;
-    asm volatile(
-        "1:\n\t"                                    // (pos < 64 here: the caller leaves its loop otherwise)
-        "s_lshl_b64 %[tmp], -1, %[pos]\n\t"
-        "s_and_b64 %[tmp], %[tmp], %[E]\n\t"
-        "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first event at or after pos (-1: none)
-        "s_cmp_lt_i32 %[e], 0\n\t"
-        "s_cbranch_scc1 30f\n"
-        "9:\n\t"
-        ZZ_L1_HOP("%[e]", "%[e2]", "4f") "s_cbranch_scc0 31f\n\t"
-        ZZ_L1_HOP("%[e2]", "%[e]", "41f") "s_cbranch_scc1 9b\n\t"
-        "s_and_b32 %[len], %[inf], 31\n\t"          // no further event: the position behind the last match
-        "s_add_u32 %[pos], %[e2], %[len]\n\t"
-        "s_branch 30f\n"
-        "31:\n\t"
-        "s_and_b32 %[len], %[inf], 31\n\t"
-        "s_add_u32 %[pos], %[e], %[len]\n"
-        "30:\n\t"
-        "s_max_u32 %[pos], %[pos], %[nact]\n\t"     // the rest of the group are literals
-        "s_branch 3f\n"
-        "5:\n\t"
-        "s_bitset1_b64 %[mst], %[e]\n\t"            // (matches found through the in-group candidate logic)
-        "s_bfm_b64 %[tmp], %[len], %[e]\n\t"
-        "s_or_b64 %[cov], %[cov], %[tmp]\n\t"
-        "s_add_u32 %[pos], %[e], %[len]\n\t"
-        "s_cmp_lt_u32 %[pos], 64\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_branch 3f\n"
-        "41:\n\t"
-        "s_mov_b32 %[e], %[e2]\n"
-        "4:\n\t"
-        "s_mov_b32 %[pos], %[e]\n\t"                // every lane below this event is decided
-        "s_bitcmp1_b32 %[inf], 17\n\t"              // not DUP (so EXTA only): leave
-        "s_cbranch_scc0 3f\n\t"
-        "s_bfe_u32 %[q], %[inf], 0x6000b\n\t"       // the nearest earlier lane with my hash
-        "s_bitcmp1_b64 %[mst], %[q]\n\t"            // visited as a match start?
-        "s_cbranch_scc1 6f\n\t"
-        "s_bitcmp0_b64 %[cov], %[q]\n\t"            // visited as a literal?
-        "s_cbranch_scc1 6f\n\t"
-        "s_bitcmp1_b32 %[inf], 18\n\t"              // skipped, and further lanes share the hash (HARD): leave
-        "s_cbranch_scc1 3f\n\t"
-        "s_bitcmp1_b32 %[inf], 19\n\t"              // skipped: the table's candidate; EXTA: leave
-        "s_cbranch_scc1 3f\n\t"
-        "s_and_b32 %[len], %[inf], 31\n\t"
-        "s_cmp_lt_u32 %[len], 4\n\t"
-        "s_cbranch_scc0 5b\n\t"
-        "s_branch 8f\n"
-        "6:\n\t"
-        "s_bitcmp1_b32 %[inf], 20\n\t"              // visited: the candidate is lane q (the most recent); EXTB: leave
-        "s_cbranch_scc1 3f\n\t"
-        "s_bfe_u32 %[len], %[inf], 0x50006\n\t"
-        "s_cmp_lt_u32 %[len], 4\n\t"
-        "s_cbranch_scc1 8f\n\t"
-        "s_bitset1_b64 %[usedB], %[e]\n\t"
-        "s_branch 5b\n"
-        "8:\n\t"
-        "s_add_u32 %[pos], %[e], 1\n\t"             // a literal after all (encoder.cpp:367)
-        "s_cmp_lt_u32 %[pos], 64\n\t"
-        "s_cbranch_scc1 1b\n"
+#define ZZ_L1_WALK_BODY \
+        "9:\n\t" \
+        ZZ_L1_HOP("%[e]", "%[e2]", "4f") "s_cbranch_scc0 31f\n\t" \
+        ZZ_L1_HOP("%[e2]", "%[e]", "41f") "s_cbranch_scc1 9b\n\t" \
+        "s_and_b32 %[len], %[inf], 31\n\t"          /* no further event: the position behind the last match */ \
+        "s_add_u32 %[pos], %[e2], %[len]\n\t" \
+        "s_branch 30f\n" \
+        "31:\n\t" \
+        "s_and_b32 %[len], %[inf], 31\n\t" \
+        "s_add_u32 %[pos], %[e], %[len]\n" \
+        "30:\n\t" \
+        "s_max_u32 %[pos], %[pos], %[nact]\n\t"     /* the rest of the group are literals */ \
+        "s_branch 3f\n" \
+        "5:\n\t" \
+        "s_bitset1_b64 %[mst], %[e]\n\t"            /* (matches found through the in-group candidate logic) */ \
+        "s_bfm_b64 %[tmp], %[len], %[e]\n\t" \
+        "s_or_b64 %[cov], %[cov], %[tmp]\n\t" \
+        "s_add_u32 %[pos], %[e], %[len]\n\t" \
+        "s_cmp_lt_u32 %[pos], 64\n\t" \
+        "s_cbranch_scc0 3f\n" \
+        "1:\n\t"                                    /* (pos < 64 here) */ \
+        "s_lshl_b64 %[tmp], -1, %[pos]\n\t" \
+        "s_and_b64 %[tmp], %[tmp], %[E]\n\t" \
+        "s_ff1_i32_b64 %[e], %[tmp]\n\t"            /* first event at or after pos (-1: none) */ \
+        "s_cmp_lt_i32 %[e], 0\n\t" \
+        "s_cbranch_scc0 9b\n\t" \
+        "s_branch 30b\n" \
+        "41:\n\t" \
+        "s_mov_b32 %[e], %[e2]\n" \
+        "4:\n\t" \
+        "s_mov_b32 %[pos], %[e]\n\t"                /* every lane below this event is decided */ \
+        "s_bitcmp1_b32 %[inf], 17\n\t"              /* not DUP (so EXTA only): leave */ \
+        "s_cbranch_scc0 3f\n\t" \
+        "s_bfe_u32 %[q], %[inf], 0x6000b\n\t"       /* the nearest earlier lane with my hash */ \
+        "s_bitcmp1_b64 %[mst], %[q]\n\t"            /* visited as a match start? */ \
+        "s_cbranch_scc1 6f\n\t" \
+        "s_bitcmp0_b64 %[cov], %[q]\n\t"            /* visited as a literal? */ \
+        "s_cbranch_scc1 6f\n\t" \
+        "s_bitcmp1_b32 %[inf], 18\n\t"              /* skipped, and further lanes share the hash (HARD): leave */ \
+        "s_cbranch_scc1 3f\n\t" \
+        "s_bitcmp1_b32 %[inf], 19\n\t"              /* skipped: the table's candidate; EXTA: leave */ \
+        "s_cbranch_scc1 3f\n\t" \
+        "s_and_b32 %[len], %[inf], 31\n\t" \
+        "s_cmp_lt_u32 %[len], 4\n\t" \
+        "s_cbranch_scc0 5b\n\t" \
+        "s_branch 8f\n" \
+        "6:\n\t" \
+        "s_bitcmp1_b32 %[inf], 20\n\t"              /* visited: the candidate is lane q (the most recent); EXTB: leave */ \
+        "s_cbranch_scc1 3f\n\t" \
+        "s_bfe_u32 %[len], %[inf], 0x50006\n\t" \
+        "s_cmp_lt_u32 %[len], 4\n\t" \
+        "s_cbranch_scc1 8f\n\t" \
+        "s_bitset1_b64 %[usedB], %[e]\n\t" \
+        "s_branch 5b\n" \
+        "8:\n\t" \
+        "s_add_u32 %[pos], %[e], 1\n\t"             /* a literal after all (encoder.cpp:367) */ \
+        "s_cmp_lt_u32 %[pos], 64\n\t" \
+        "s_cbranch_scc1 1b\n" \
         "3:\n\t"
-        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e), [e2] "=&s"(e2),
-          [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q)
-        : [E] "s"(E), [info] "v"(info), [nact] "s"(nact)
-        : "scc");
+#define ZZ_L1_WALK_OPERANDS \
+        : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e), [e2] "=&s"(e2), \
+          [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q) \
+        : [E] "s"(E), [info] "v"(info), [nact] "s"(nact) \
+        : "scc"
+    if (FIRST)
+        asm volatile(
+            "s_ff1_i32_b64 %[e], %[E]\n\t"              // the group's first event (-1: none)
+            "s_cmp_lt_i32 %[e], 0\n\t"
+            "s_cbranch_scc1 30f\n"
+            ZZ_L1_WALK_BODY ZZ_L1_WALK_OPERANDS);
+    else
+        asm volatile(
+            "s_cmp_gt_u32 %[pos], 63\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "s_branch 1f\n"
+            ZZ_L1_WALK_BODY ZZ_L1_WALK_OPERANDS);
+#undef ZZ_L1_WALK_BODY
+#undef ZZ_L1_WALK_OPERANDS
 }
 
 // a committed token as it waits one iteration for emission: bit31 match (len<<16 | dist), bit30 literal (byte)
@@ -376,11 +394,11 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             // (selects, not a lane-mask region: a lane alone with its hash has nothing below it and ends up with info = 0)
             const uint64_t below = myset & below_me;                      // earlier lanes with my hash
             const bool dup = below != 0 && active;                        // (a lane past the end may sit in a set: never an event)
-            const uint32_t ql = dup ? 63u - (uint32_t)__builtin_clzll(below | 1ull) : (uint32_t)lane;
+            const uint32_t ql = 63u - (uint32_t)__builtin_clzll(below | 1ull);   // (lane 0 where there is none: result unused)
             // the in-group candidate's bytes come from its lane's registers, while the table candidate's are still in flight
-            // (ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part)
-            const uint64_t wq = ((uint64_t)(uint32_t)__shfl((int)(w >> 32), (int)ql) << 32) | (uint32_t)__shfl((int)w, (int)ql);
-            const uint64_t wq2 = ((uint64_t)(uint32_t)__shfl((int)(w2 >> 32), (int)ql) << 32) | (uint32_t)__shfl((int)w2, (int)ql);
+            const int qa = (int)(ql << 2);
+            const uint64_t wq = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w);
+            const uint64_t wq2 = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w2 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w2);
             const uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
             const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | ((uint32_t)__builtin_popcountll(myset) > 2u ? ZZ_WI_HARD : 0u)   // ... shared by more than two lanes
                                 | (lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT));
@@ -414,9 +432,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events (length | 0x8000) ...
         uint64_t ovmL = 0, ovmC = 0;             // ... and the lanes that hold one
         uint32_t pos = 0;
-        for (;;) {
-            l1_fast_walk(E, info, nact, pos, mst, cov, usedB);
-            if (pos >= nact) break;
+        l1_fast_walk<true>(E, info, nact, pos, mst, cov, usedB);
+        while (pos < nact) {
             const int e = (int)pos;                                     // the walk stopped AT an event it cannot decide
             ZZ_C(11, 1);
             const uint64_t probed = ~cov | mst;                         // lanes below e the parse has visited
@@ -466,7 +483,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             } else {
                 pos = (uint32_t)e + 1;                                   // a literal after all (encoder.cpp:367)
             }
-            if (pos >= nact) break;
+            l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB);
         }
         ZZ_T(6);
         // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
@@ -483,7 +500,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // next group's bytes: in flight while this group is repaired
         uint64_t wnext = 0, wnext2 = 0;
         if (MASKED) { if (next + (uint32_t)lane < n) ld128<SAFE>(src + next + lane, end, wnext, wnext2); }
-        else if (next < n) ld128<SAFE>(src + (next + (uint32_t)lane < n ? next + (uint32_t)lane : n - 1), end, wnext, wnext2);
+        else if (INTERIOR || next < n)      // (interior copy: no branch; a finished packet reads its last byte once more)
+            ld128<SAFE>(src + (next + (uint32_t)lane < n ? next + (uint32_t)lane : n - 1), end, wnext, wnext2);
 
         // (4) table repair: skipped lanes restore the old entry; among committed lanes sharing a hash the
         // highest position wins -- the state the serial loop leaves behind
@@ -518,7 +536,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             const uint32_t cn = sel_lanes(ovmC, ovcand1, sel_lanes(usedB, cur + ZZ_WI_QLANE(info) + 1 + BIAS, old));
             const uint32_t tmatch = (tl << 16) | (p + 1 + BIAS - cn);
             const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
-            ptok = keep_lanes(committed, sel_lanes(mst, tmatch, tlit)) | (next >= n ? ZZ_TOK_LAST : 0u);
+            ptok = keep_lanes(committed, sel_lanes(mst, tmatch, tlit));
+            if (!INTERIOR) ptok |= next >= n ? ZZ_TOK_LAST : 0u;          // (a packet that ends in an interior group: see below)
         } else {   // (masks, not branches: the values are cheap and a lane-mask region is three scalar instructions)
             const uint32_t mB = 0u - (uint32_t)((usedB >> lane) & 1);          // all ones where the in-group candidate matched
             const uint32_t la_ = ZZ_WI_LENA(info), ca_ = old;
@@ -551,9 +570,16 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_T(8);
     };
     if (SPLIT) while (cur + ZZ_WAVE + ZZ_WI_CAP <= n) group(std::true_type{});     // lane 63 has 17 bytes left
+    const bool flagged = cur < n;                                       // the last group will carry ZZ_TOK_LAST
     while (cur < n) group(std::false_type{});
     if (!SPLIT) l1_emit_tokens(ring, lcodes, ptok);
-    else l1_group_barrier();                                            // the last group's hand-over
+    else {
+        if (!flagged) {         // a long match ended the packet inside an interior group: an empty group carries the flag
+            l1_group_barrier();
+            *slot = ZZ_TOK_LAST;
+        }
+        l1_group_barrier();                                             // the last group's hand-over
+    }
     ZZ_PROF_FLUSH(P);
 }
 
