@@ -532,64 +532,84 @@ __device__ __forceinline__ uint32_t l2_probe_blocks(uint32_t n)     // trips of 
 // BIAS = 32768: warm window (the extended levels 4..6, see zz_api.hip): table entries are position + 1 + BIAS, the
 // positions -32768 .. -1 in front of the packet were hashed into the table by the caller; candidates 32768 or more back
 // are ignored (encoder.cpp:392).
+// ffbh with the same "-1 for 0" as ffbl_or_ones, for equal TRAILING bytes (the bytes in front of a position)
+__device__ __forceinline__ uint32_t ffbh_or_ones(uint32_t v)
+{
+    uint32_t r;
+    asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_from4_sat(uint32_t v)           // max(4 - v, 0)
+{
+    uint32_t r;
+    asm("v_sub_u32_e64 %0, 4, %1 clamp" : "=v"(r) : "v"(v));
+    return r;
+}
+
 template <bool SAFE, uint32_t BIAS = 0>
 __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const uint8_t* src, const uint8_t* end,
                                               uint32_t n, uint64_t before, unsigned long long* prof = nullptr)
 {
     const int lane = lane_id();
+    const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
     ZZ_PROF_DECL
     const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
     uint32_t B = 1;                 // backRefEnd (:380)
     uint32_t nextProbe = 1;         // j (:383)
     uint32_t batchEnd = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
     uint32_t skipPos = 0;           // position that must not be inserted in the current block (0 = byte 0)
+    // bytes in front of the packet, as far as they matter: a candidate at offset c has min(before + c, 258) bytes of room
+    // behind it (D4 + D11 caps), and offsets below lo8 have fewer than the 8 bytes the backward compare loads
+    const uint32_t bcap = (uint32_t)(before < ZZ_MAX_LEN ? before : ZZ_MAX_LEN);
+    const uint32_t lo8 = before >= 8 ? 0u : 8u - (uint32_t)before;
+    const uint8_t* const srcm8 = src - 8;
     // this lane's own bytes: 16 from its position (hash + forward compare) and the 8 in front (backward compare)
     uint64_t wa = 0, wa2 = 0, wb = 0;
     if ((uint32_t)lane < n) {
         ld128<SAFE>(src + lane, end, wa, wa2);
         if (before + (uint32_t)lane >= 8) wb = load64(src + (int64_t)lane - 8);
     }
-    for (uint32_t base = 0; base < target; base += 64) {
-        if (base >= batchEnd) {
-            // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first
-            // byte is inserted only if the last match covered it
-            const uint32_t s2 = B > batchEnd ? B : batchEnd;
-            skipPos = B >= batchEnd ? 0xFFFFFFFFu : batchEnd;
-            B = s2 + 1;
-            nextProbe = s2 + 1;
-            const uint32_t rest = target - s2;
-            batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
-        }
+    uint32_t slotsel = 0;           // word offset of the hand-over slot in use (alternates)
+    // One block of 64 positions. Every position of a block lies below target = n - 258, so its own 16-byte loads, the
+    // next block's and every candidate's stay inside the packet: no bounds checks and no clamps anywhere here.
+    // INTERIOR: not the packet's first block, no position excluded from the table, the whole block inside the current
+    // batch and some position of it probed -- the common case; the lane conditions and their scalar bookkeeping (every
+    // lane-mask region is three scalar instructions, and the CU's one scalar unit is what this kernel is short of)
+    // drop out of that copy of the code.
+    auto block = [&](auto interior_tag, const uint32_t base) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
         ZZ_T(6);
         const uint32_t q = base + lane;
-        const bool ins = q < n && q != skipPos && q != 0;
-        const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
+        const bool ins = INTERIOR ? true : (q != skipPos && q != 0);
+        const bool doProbe = INTERIOR ? true : (base + 64 > nextProbe && nextProbe < batchEnd);   // some position of this block is probed
         const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
-        // lanes that must not insert (past the end, byte 0, a batch's first byte) read and write a slot of their own behind
-        // the kernel's other LDS data instead: no lane mask, i.e. no scalar instructions, around the table accesses
+        // lanes that must not insert (byte 0, a batch's first byte) read and write a slot of their own behind the kernel's
+        // other LDS data instead: no lane mask around the table accesses
         const uint32_t hs = ins ? h : (uint32_t)(ZZ_L2_LDS_BYTES / 2);
         uint32_t old = T[hs];                                         // :389
         T[hs] = (uint16_t)(q + 1 + BIAS);                             // :390 / :474-480
         if (!ins) old = 0;
         if (BIAS && q + 1 + BIAS - old >= 32768u) old = 0;            // :392 (inside a cold packet every candidate is in reach)
         // the table candidate's bytes are requested at once (a lane whose candidate turns out to sit in this very
-        // block takes that lane's registers instead): 16 at the candidate (:399), 8 in front of it (:92-102)
-        // Every lane loads, from a clamped address where it has nothing to load (the result is not looked at): a lane
-        // mask around a load costs three scalar instructions, and the CU's one scalar unit is what this kernel is short of.
+        // block takes that lane's registers instead): 16 at the candidate (:399), 8 in front of it (:92-102).
+        // Every lane loads (a lane without a candidate: the packet's first bytes, result not looked at).
         uint64_t ca = 0, ca2 = 0, cpre = 0;
         if (doProbe) {
-            const int32_t c0 = old ? (int32_t)(old - 1 - BIAS) : 0;
-            ld128<SAFE>(src + c0, end, ca, ca2);
-            cpre = load64(src + ((int64_t)before + c0 >= 8 ? (int64_t)c0 - 8 : 0));
+            if (BIAS == 0) {
+                const uint32_t c0 = __builtin_elementwise_sub_sat(old, 1u);
+                ld128<false>(src + c0, end, ca, ca2);
+                cpre = load64(srcm8 + (c0 > lo8 ? c0 : lo8));          // (too close to the stream's start: fixed up below)
+            } else {
+                const int32_t c0 = old ? (int32_t)(old - 1 - BIAS) : 0;
+                ld128<false>(src + c0, end, ca, ca2);
+                cpre = load64(src + ((int64_t)before + c0 >= 8 ? (int64_t)c0 - 8 : 0));
+            }
         }
         // next block's own bytes: in flight during the rest of this block
         uint64_t wan, wan2, wbn;
-        {
-            const uint32_t qn = q + 64 < n ? q + 64 : n - 1;
-            ld128<SAFE>(src + qn, end, wan, wan2);
-            wbn = load64(src + (qn >= 8 ? qn - 8 : 0));
-        }
-        if (base) l2_block_barrier();     // releases the previous block's matches to the helper (the table read above had to land anyway)
+        ld128<false>(src + q + 64, end, wan, wan2);
+        wbn = load64(src + q + 56);
+        if (INTERIOR || base) l2_block_barrier();   // releases the previous block's matches to the helper (the table read above had to land anyway)
         ZZ_WAVE_SYNC();
         // Positions of this block that share a hash: the read-back names the lane whose store landed, the same
         // lane for every member of a set and a different one for different sets -- a 6-bit key. Six ballots give
@@ -597,46 +617,68 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
         // earlier member, and the table must end up holding the last member.
         const uint32_t rb = T[hs];
         uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
-        int inlane = -1;                                              // >= 0: the candidate is that lane of this block
-        if (ballot(ins && rb != q + 1 + BIAS)) {
+        bool inl = false;                                             // the candidate is lane `il` of this block
+        uint32_t il = 0;
+        const uint64_t lost = INTERIOR ? ballot(rb != q + 1 + BIAS) : ballot(ins && rb != q + 1 + BIAS);
+        if (lost) {
             const uint32_t W = ins ? (rb - 1u - BIAS - base) & 63u : (uint32_t)lane;
             const uint64_t set = wave_match6(W);
-            const uint64_t below = set & ((1ull << lane) - 1);
-            if (ins && below) { inlane = 63 - __builtin_clzll(below); cand1 = base + (uint32_t)inlane + 1 + BIAS; }   // nearest earlier member
+            const uint64_t below = set & below_me;
+            inl = ins && below != 0;
+            il = 63u - (uint32_t)__builtin_clzll(below | 1ull);       // nearest earlier member (lane 0 where there is none: unused)
+            cand1 = inl ? base + il + 1 + BIAS : old;
             ZZ_WAVE_SYNC();
-            if (ins && W != (uint32_t)lane && (set >> lane) >> 1 == 0) T[h] = (uint16_t)(q + 1 + BIAS);   // last member wins
+            // last member wins: the highest lane of a set rewrites the slot unless its own store was the one that landed
+            if (INTERIOR) {
+                const uint64_t fix = ballot(W != (uint32_t)lane) & ballot((set & above_me) == 0);
+                uint64_t saved;
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(fix), "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)(T + h)), "v"(q + 1 + BIAS)
+                             : "memory", "scc");
+            } else if (ins && W != (uint32_t)lane && (set & above_me) == 0) T[h] = (uint16_t)(q + 1 + BIAS);
         }
         ZZ_WAVE_SYNC();
         skipPos = 0xFFFFFFFFu;   // only the block that contains it skips (byte 0 is excluded by q != 0)
 
         ZZ_T(7);
+        uint32_t* slot = hb + slotsel;
+        slotsel ^= ZZ_L2_HB_WORDS;
         if (doProbe) {
             // ---- quick compare info for all 64 probes of this block --------------------------------------
-            const bool has = ins && cand1 != 0 && q < batchEnd;
+            const bool has = INTERIOR ? cand1 != 0 : (ins && cand1 != 0 && q < batchEnd);
             const int32_t c = (int32_t)(cand1 - 1 - BIAS);           // may lie in front of the packet (warm window)
-            if (ballot(inlane >= 0)) {
-                // ds_bpermute returns 0 for source lanes that are switched off, so every lane takes part
-                const int sl = inlane >= 0 ? inlane : lane;
-                const uint64_t sa = ((uint64_t)(uint32_t)__shfl((int)(wa >> 32), sl) << 32) | (uint32_t)__shfl((int)wa, sl);
-                const uint64_t sa2 = ((uint64_t)(uint32_t)__shfl((int)(wa2 >> 32), sl) << 32) | (uint32_t)__shfl((int)wa2, sl);
-                const uint64_t sp = ((uint64_t)(uint32_t)__shfl((int)(wb >> 32), sl) << 32) | (uint32_t)__shfl((int)wb, sl);
-                if (inlane >= 0) { ca = sa; ca2 = sa2; cpre = sp; }
+            if (lost) {
+                // candidates inside the block: their bytes come from the owning lane's registers
+                const int qa = (int)(il << 2);
+                const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(wa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)wa);
+                const uint64_t sa2 = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(wa2 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)wa2);
+                const uint64_t sp = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(wb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)wb);
+                if (inl) { ca = sa; ca2 = sa2; cpre = sp; }
             }
-            // (selects rather than branches, for the same reason; only the first eight bytes of a stream take the loop)
             uint32_t fwd8, bwd8, room;
             {
-                const uint64_t cb = (uint64_t)((int64_t)before + c);   // bytes in front of the candidate
-                room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;    // D4 + D11 caps
-                const uint64_t y = wb ^ cpre;
-                bwd8 = (y ? (uint32_t)__builtin_clzll(y) : 64u) >> 3;
-                if (has && room < 8) {
-                    bwd8 = 0;
-                    while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
+                if (BIAS == 0) {
+                    const uint32_t r = bcap + (uint32_t)c;                 // bytes in front of the candidate, as far as they count
+                    room = r < ZZ_MAX_LEN ? r : ZZ_MAX_LEN;                // D4 + D11 caps
+                } else {
+                    const uint64_t cb = (uint64_t)((int64_t)before + c);
+                    room = cb < ZZ_MAX_LEN ? (uint32_t)cb : ZZ_MAX_LEN;
                 }
-                fwd8 = equal_bytes16(wa ^ ca, wa2 ^ ca2);              // 16 bytes at the probe and at the candidate (:399); 16 = "16 or more"
-                if (!has) { fwd8 = 0; bwd8 = 0; room = 0; }
+                // equal bytes in front of the probe and in front of the candidate: leading zero bits of the XOR of the two
+                // words that end there, 8 = "8 or more" (ffbh gives -1 for 0, the addition saturates, min3 caps)
+                const uint64_t y = wb ^ cpre;
+                bwd8 = umin3(ffbh_or_ones((uint32_t)(y >> 32)), add_sat_k<32>(ffbh_or_ones((uint32_t)y)), 64u) >> 3;
+                if (before < 8 && ballot(has && room < 8)) {           // only in the first bytes of a stream: byte by byte
+                    if (has && room < 8) {
+                        bwd8 = 0;
+                        while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
+                    }
+                }
+                fwd8 = equal_bits128(wa ^ ca, wa2 ^ ca2, 128u) >> 3;   // 16 bytes at the probe and at the candidate (:399); 16 = "16 or more"
+                if (!has) fwd8 = 0;
             }
-            const uint32_t broom = bwd8 < room ? bwd8 : room;
+            uint32_t broom = bwd8 < room ? bwd8 : room;
+            if (!has) broom = 0;
             ZZ_DRAIN();
             ZZ_T(8);
             // ---- the greedy walk ----------------------------------------------------------------------------------
@@ -646,17 +688,15 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             // only hops from match to match (scalar code is slow here: tools/ubench_scalar.hip) and marks the lanes;
             // starts and lengths are computed for all marked lanes at once afterwards. Lengths of "16 or more"
             // forward / "8 or more" backward drop out to the C++ below.
-            const bool strong = has && fwd8 >= 4;
-            const bool weak = has && fwd8 < 4 && fwd8 + broom >= 4;
-            const uint64_t Smask = ballot(strong);
-            const uint64_t Amask = Smask | ballot(weak);
-            uint32_t winfo = fwd8 | ((weak ? 4 - fwd8 : 0) << 5) | (broom == 8 ? 0x100u : 0) | (fwd8 == 16 ? 0x200u : 0) |
-                             (strong ? 0x800u : 0) | (strong && broom != 8 && fwd8 != 16 ? 0x400u : 0) |
-                             (((uint32_t)lane + fwd8) << 23);
+            const uint64_t Amask = ballot(fwd8 + broom >= 4);                     // strong or weak
+            const uint32_t inexact = (fwd8 & 16u) | (broom & 8u);                // "16 or more" forward (-> bit 9) | "8 or more" backward (-> bit 8)
+            uint32_t winfo = fwd8 | (sub_from4_sat(fwd8) << 5) | (inexact << 5) | (((fwd8 + 28u) & 32u) << 6) |   // fwd8 >= 4: strong, bit 11
+                             ((fwd8 >= 4 && inexact == 0) ? 0x400u : 0u) | (((uint32_t)lane + fwd8) << 23);
             {
                 const uint32_t endl = (uint32_t)lane + fwd8 + 1;                  // first lane probed after a match here
-                const uint64_t m = endl >= 64 ? 0 : (Amask & (~0ull << endl));
-                winfo |= (m ? (uint32_t)__builtin_ctzll(m) : 0u) << 16;
+                const uint64_t m = Amask >> (endl & 63u);                         // (endl >= 64: whatever this finds lies at 64 or beyond)
+                const uint32_t nx = endl + (m ? (uint32_t)__builtin_ctzll(m) : 64u);
+                winfo |= ((nx < 64u ? nx : 64u) & 63u) << 16;                     // (64 & 63 = 0 = none)
             }
             uint32_t tk = 0;                // start | len << 16, slow tokens only; the others are filled in below
             uint64_t evmask = 0, slowmask = 0;
@@ -750,22 +790,32 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             }
             ZZ_T(9);
             // ---- hand this block's matches to the helper wavefront (which also fills in the starts and lengths of the
-            // matches the scalar loop only marked) ---------------------------------------------------------------------
-            uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
-            if ((evmask >> lane) & 1)
-                slot[lane] = ((slowmask >> lane) & 1) ? ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, (uint32_t)((int32_t)q - c), base)
-                                                      : ZZ_L2_HB_PACK_FAST(fwd8, broom, (uint32_t)((int32_t)q - c));
-            if (lane == 0) {
-                slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32);
-                slot[66] = (uint32_t)slowmask; slot[67] = (uint32_t)(slowmask >> 32);
-                slot[68] = Bentry;
-            }
-        } else if (lane == 0) {
-            uint32_t* slot = hb + ((base >> 6) & 1) * ZZ_L2_HB_WORDS;
+            // matches the scalar loop only marked). Every lane stores (a lane without a match: a word nobody looks at; the
+            // masks and backRefEnd: the same words from all lanes) -- no lane mask to set up.
+            const uint32_t dist = (uint32_t)((int32_t)q - c);
+            slot[lane] = sel_lanes(slowmask, ZZ_L2_HB_PACK(tk & 0xFFFF, tk >> 16, dist, base), ZZ_L2_HB_PACK_FAST(fwd8, broom, dist));
+            slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32);
+            slot[66] = (uint32_t)slowmask; slot[67] = (uint32_t)(slowmask >> 32);
+            slot[68] = Bentry;
+        } else {
             slot[64] = 0; slot[65] = 0;
         }
         ZZ_T(12);
         wa = wan; wa2 = wan2; wb = wbn;
+    };
+    for (uint32_t base = 0; base < target; base += 64) {
+        if (base >= batchEnd) {
+            // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first
+            // byte is inserted only if the last match covered it
+            const uint32_t s2 = B > batchEnd ? B : batchEnd;
+            skipPos = B >= batchEnd ? 0xFFFFFFFFu : batchEnd;
+            B = s2 + 1;
+            nextProbe = s2 + 1;
+            const uint32_t rest = target - s2;
+            batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
+        }
+        if (base >= 64 && skipPos == 0xFFFFFFFFu && base + 64 <= batchEnd && base + 64 > nextProbe) block(std::true_type{}, base);
+        else block(std::false_type{}, base);
     }
     if (target) l2_block_barrier();       // the last block's matches
 #ifdef ZZ_PROF
