@@ -366,6 +366,16 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             ld128<SAFE>(src + __builtin_elementwise_sub_sat(old, 1u), end, wc, wc2);
         else
             ld128<SAFE>(src + (old ? (int32_t)(old - 1 - BIAS) : (int32_t)start), end, wc, wc2);  // encoder.cpp:350
+        // Interior groups: this lane's bytes for the NEXT group are requested now, a whole group ahead of their use, on the
+        // guess that this group ends 0..16 positions past its last lane (the overshoot of its last match): 32 bytes from
+        // position cur + 64 + lane. Where the guess holds the next group's 16 bytes are cut out of these registers
+        // (v_alignbyte, below) and no load sits between two groups any more -- that wait for the L2 was 15 % of a group's
+        // time (phase stamps); where it does not, the load happens as before.
+        uint64_t sA = 0, sA2 = 0, sB = 0, sB2 = 0;
+        if (INTERIOR) {
+            ld128<SAFE>(src + cur + ZZ_WAVE + lane, end, sA, sA2);
+            ld128<SAFE>(src + cur + ZZ_WAVE + 16 + lane, end, sB, sB2);
+        }
         if (SPLIT) l1_group_barrier();                                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
@@ -500,6 +510,22 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // next group's bytes: in flight while this group is repaired
         uint64_t wnext = 0, wnext2 = 0;
         if (MASKED) { if (next + (uint32_t)lane < n) ld128<SAFE>(src + next + lane, end, wnext, wnext2); }
+        else if (INTERIOR && pos <= ZZ_WAVE + 16) {
+            // the guess held: bytes d .. d+15 of the 32 requested at the top of the group (d = pos - 64, uniform)
+            const uint32_t d = pos - ZZ_WAVE, sh = d & 3u;
+            const uint32_t b0 = (uint32_t)sA, b1 = (uint32_t)(sA >> 32), b2 = (uint32_t)sA2, b3 = (uint32_t)(sA2 >> 32);
+            const uint32_t b4 = (uint32_t)sB, b5 = (uint32_t)(sB >> 32), b6 = (uint32_t)sB2, b7 = (uint32_t)(sB2 >> 32);
+            uint32_t r0, r1, r2, r3;
+            switch (d >> 2) {
+            case 0: r0 = __builtin_amdgcn_alignbyte(b1, b0, sh); r1 = __builtin_amdgcn_alignbyte(b2, b1, sh); r2 = __builtin_amdgcn_alignbyte(b3, b2, sh); r3 = __builtin_amdgcn_alignbyte(b4, b3, sh); break;
+            case 1: r0 = __builtin_amdgcn_alignbyte(b2, b1, sh); r1 = __builtin_amdgcn_alignbyte(b3, b2, sh); r2 = __builtin_amdgcn_alignbyte(b4, b3, sh); r3 = __builtin_amdgcn_alignbyte(b5, b4, sh); break;
+            case 2: r0 = __builtin_amdgcn_alignbyte(b3, b2, sh); r1 = __builtin_amdgcn_alignbyte(b4, b3, sh); r2 = __builtin_amdgcn_alignbyte(b5, b4, sh); r3 = __builtin_amdgcn_alignbyte(b6, b5, sh); break;
+            case 3: r0 = __builtin_amdgcn_alignbyte(b4, b3, sh); r1 = __builtin_amdgcn_alignbyte(b5, b4, sh); r2 = __builtin_amdgcn_alignbyte(b6, b5, sh); r3 = __builtin_amdgcn_alignbyte(b7, b6, sh); break;
+            default: r0 = b4; r1 = b5; r2 = b6; r3 = b7; break;       // d = 16
+            }
+            wnext = ((uint64_t)r1 << 32) | r0;
+            wnext2 = ((uint64_t)r3 << 32) | r2;
+        }
         else if (INTERIOR || next < n)      // (interior copy: no branch; a finished packet reads its last byte once more)
             ld128<SAFE>(src + (next + (uint32_t)lane < n ? next + (uint32_t)lane : n - 1), end, wnext, wnext2);
 
@@ -569,7 +595,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         w2 = wnext2;
         ZZ_T(8);
     };
-    if (SPLIT) while (cur + ZZ_WAVE + ZZ_WI_CAP <= n) group(std::true_type{});     // lane 63 has 17 bytes left
+    // (lane 63 has 17 bytes left, and the 32 bytes requested for the next group lie inside the block: cur + 64 + 63 + 32 <= n)
+    if (SPLIT) while (cur + 2 * ZZ_WAVE + 32 <= n) group(std::true_type{});
     const bool flagged = cur < n;                                       // the last group will carry ZZ_TOK_LAST
     while (cur < n) group(std::false_type{});
     if (!SPLIT) l1_emit_tokens(ring, lcodes, ptok);
@@ -682,6 +709,9 @@ __device__ __forceinline__ void l1_packet_emitter(const zz_packet_params& P, uin
 {
     const int lane = lane_id();
     const l1_pk q = l1_packet_of(P, k);
+#ifdef ZZ_L1_EMIT_PRIO
+    __builtin_amdgcn_s_setprio(ZZ_L1_EMIT_PRIO);
+#endif
     bitring ring;
     ring_init(ring, ring_words, q.out);
     if (P.cks_kind == ZZ_CKS_ADLER) {     // while the parser works on its first groups

@@ -701,13 +701,13 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             uint32_t tk = 0;                // start | len << 16, slow tokens only; the others are filled in below
             uint64_t evmask = 0, slowmask = 0;
             const uint32_t Bentry = B;
-            for (;;) {
-                uint32_t np = nextProbe > base ? nextProbe - base : 0;   // first lane that may be probed
-                if (np >= 64) break;
+            // positions relative to the block while the walk runs: np = first lane that may be probed (< 64 on entry: some
+            // position of this block is probed), Brel = backRefEnd
+            uint32_t np = (int32_t)(nextProbe - base) > 0 ? nextProbe - base : 0u;
+            int32_t Brel = (int32_t)(B - base);
+            for (bool first = true;; first = false) {
                 uint32_t slow = 0;
-                int32_t Brel = (int32_t)uniform(B - base);               // the compiler does not always see that these are wave-uniform
-                np = uniform(np);
-                {
+                if (first || np < 64) {
                     uint32_t inf, t1, t2;
                     uint64_t tmp;
                     int32_t e;
@@ -761,14 +761,12 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                         : [winfo] "v"(winfo), [A] "s"(Amask)
                         : "scc");
                 }
-                B = base + (uint32_t)Brel;
-                nextProbe = base + np;
                 if (!slow) break;
                 // one token with a length of "8 or more" backward or "16 or more" forward, at lane np
                 const int e = (int)np;
                 const uint32_t qe = base + (uint32_t)e;
                 uint32_t fwd = readlane(fwd8, e);
-                const uint32_t pe = qe - B;                              // j - backRefEnd (:404)
+                const uint32_t pe = (uint32_t)(e - Brel);                // j - backRefEnd (:404)
                 const uint32_t bre = readlane(broom, e);
                 uint32_t bw = bre < pe ? bre : pe;
                 {
@@ -781,13 +779,14 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 uint32_t mlen = fwd + bw;
                 if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                           // :412-415
                 const uint32_t ms = qe - bw;                                                        // :416
-                B = ms + mlen;                                                                      // :422
+                Brel = (int32_t)(ms + mlen - base);                                                 // :422
                 if (lane == e) tk = ms | (mlen << 16);                                              // :420
                 evmask |= 1ull << e;
                 slowmask |= 1ull << e;
-                nextProbe = B + 1;                                                                  // :424
-                if (nextProbe >= base + 64) break;
+                np = (uint32_t)Brel + 1;                                                            // :424
             }
+            B = base + (uint32_t)Brel;
+            nextProbe = base + np;
             ZZ_T(9);
             // ---- hand this block's matches to the helper wavefront (which also fills in the starts and lengths of the
             // matches the scalar loop only marked). Every lane stores (a lane without a match: a word nobody looks at; the
