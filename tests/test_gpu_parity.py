@@ -492,6 +492,31 @@ def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
         assert enc(d, 1, lvl) == oracle.encode_packets(d, 1, lvl, warm=8192)
 
 
+def test_warm_window_candidates_at_the_very_start_of_the_stream(gpu, oracle):
+    """Regression (found by tools/fuzz_gpu.py, case 3690 of seed 9191): with a warm window a candidate may sit in the first
+    eight bytes of the STREAM while the packet that probes it has plenty of bytes in front of it, so the "fewer than 8 bytes
+    in front of the candidate" path of the level-2 backward comparison (D4 clamp, encoder.cpp:92-102) must not be tied to
+    the packet's own offset. 31,466 bytes from a short vocabulary in 1,024-byte packets."""
+    import torch
+    d = zlib.decompress(open(os.path.join(GOLDEN, "cases", "warm_candidate_in_first_bytes_of_stream.bin.z"), "rb").read())
+    ctx = zz.Context(0)
+    ctx.set_extended_levels(True)
+    try:
+        src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        for P in (1024, 777):
+            for lvl, warm in ((5, 16384), (6, 32768), (4, 4096), (2, 32768), (3, 1000)):
+                ctx.set_warm_window(warm if lvl < 4 else 0)
+                cap = zz.bound(len(d), 1, 3, P)
+                dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+                w = ctx.encode(src, len(d), dst, cap, zz.Format.Gzip, lvl, P)
+                got = dst[:w].cpu().numpy().tobytes()
+                assert got == oracle.encode_packets(d, 1, lvl if lvl < 4 else 2, P, warm=warm), (P, lvl)
+                assert zlib.decompressobj(31).decompress(got) == d
+    finally:
+        ctx.set_warm_window(0)
+        ctx.set_extended_levels(False)
+
+
 def test_warm_window_through_the_host_entry_points(gpu, oracle, corpus):
     """ZZFLATE_WARM_WINDOW for ZzFlateEncode / ZzFlateEncodeToCallback; checked in a child process because the
     variable is read once. Slabs carry the window in their halo, so the slab pipeline gives the same bytes."""

@@ -1,14 +1,16 @@
 """Extended seeded fuzz against the oracle (manual; the pytest suite runs a 120-case version): packet mode (cold, warm
 window, extended levels), the sequential stream into roomy and tight destinations, the callback form's chunks.
-python tools/fuzz_gpu.py [cases] [seed]"""
+python tools/fuzz_gpu.py [cases] [seed]
+ZZ_FUZZ_DUMP=<case> python tools/fuzz_gpu.py [cases] [seed]   (no GPU needed) writes that case's input to gpurun_out/fuzz_case_<case>.in"""
 import os, random, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import zzflate_amd as zz
 from conftest import Oracle, synth, SYNTH_KINDS
+DUMP = int(os.environ.get("ZZ_FUZZ_DUMP", "-1"))
 o = Oracle()
-ctx = zz.Context(0)
+ctx = zz.Context(0) if DUMP < 0 else None
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 WB = {0: 15, 1: 31, 2: -15}
@@ -29,8 +31,22 @@ for it in range(cases):
         d = bytes(b[:n]) if len(b) >= n else bytes(b)
     P = rng.choice([32768, 32768, 32768, 16384, 8192, 4096, 2048, 1024, 1000, 777, rng.randint(1, 32768)])
     lvl = rng.randint(0, 3); fmt = rng.randint(0, 2)
-    src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
     mode = it % 4
+    if DUMP >= 0:
+        # consume the same random numbers as a real run, without a GPU
+        if it == DUMP:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", f"fuzz_case_{it}.in"), "wb").write(d)
+            print("case", it, kind, len(d), "P", P, "lvl", lvl, "fmt", fmt, "mode", mode)
+            sys.exit(0)
+        if mode == 3 and len(d) > 0:
+            if rng.random() < 0.5:
+                rng.randint(40, 99); rng.choice([0, 1, 2])
+        else:
+            if mode >= 1: rng.choice([0, 0, 258, 1000, 4096, 32768])
+            if mode == 2 and rng.random() < 0.4: rng.choice([4, 5, 6])
+        continue
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
     if mode == 3 and len(d) > 0:
         # the reference's single-Encoder stream (threaded = false) into a tight or roomy destination, or in chunks
         if rng.random() < 0.5:

@@ -668,7 +668,9 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 // words that end there, 8 = "8 or more" (ffbh gives -1 for 0, the addition saturates, min3 caps)
                 const uint64_t y = wb ^ cpre;
                 bwd8 = umin3(ffbh_or_ones((uint32_t)(y >> 32)), add_sat_k<32>(ffbh_or_ones((uint32_t)y)), 64u) >> 3;
-                if (before < 8 && ballot(has && room < 8)) {           // only in the first bytes of a stream: byte by byte
+                // fewer than 8 bytes in front of the candidate -- only in the first bytes of a stream: byte by byte. (A cold packet's
+                // candidates lie inside it, so a packet with 8 bytes in front of it never gets here; a warm window reaches back.)
+                if ((BIAS != 0 || before < 8) && ballot(has && room < 8)) {
                     if (has && room < 8) {
                         bwd8 = 0;
                         while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
