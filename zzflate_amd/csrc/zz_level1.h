@@ -516,13 +516,35 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             const uint32_t b0 = (uint32_t)sA, b1 = (uint32_t)(sA >> 32), b2 = (uint32_t)sA2, b3 = (uint32_t)(sA2 >> 32);
             const uint32_t b4 = (uint32_t)sB, b5 = (uint32_t)(sB >> 32), b6 = (uint32_t)sB2, b7 = (uint32_t)(sB2 >> 32);
             uint32_t r0, r1, r2, r3;
-            switch (d >> 2) {
-            case 0: r0 = __builtin_amdgcn_alignbyte(b1, b0, sh); r1 = __builtin_amdgcn_alignbyte(b2, b1, sh); r2 = __builtin_amdgcn_alignbyte(b3, b2, sh); r3 = __builtin_amdgcn_alignbyte(b4, b3, sh); break;
-            case 1: r0 = __builtin_amdgcn_alignbyte(b2, b1, sh); r1 = __builtin_amdgcn_alignbyte(b3, b2, sh); r2 = __builtin_amdgcn_alignbyte(b4, b3, sh); r3 = __builtin_amdgcn_alignbyte(b5, b4, sh); break;
-            case 2: r0 = __builtin_amdgcn_alignbyte(b3, b2, sh); r1 = __builtin_amdgcn_alignbyte(b4, b3, sh); r2 = __builtin_amdgcn_alignbyte(b5, b4, sh); r3 = __builtin_amdgcn_alignbyte(b6, b5, sh); break;
-            case 3: r0 = __builtin_amdgcn_alignbyte(b4, b3, sh); r1 = __builtin_amdgcn_alignbyte(b5, b4, sh); r2 = __builtin_amdgcn_alignbyte(b6, b5, sh); r3 = __builtin_amdgcn_alignbyte(b7, b6, sh); break;
-            default: r0 = b4; r1 = b5; r2 = b6; r3 = b7; break;       // d = 16
-            }
+            // Dwords d/4 .. d/4+4 of the eight, shifted by d%4 bytes. d is uniform, so this is a jump to one of five blocks
+            // of four v_alignbyte_b32 -- written out, because the compiler's lowering of the switch cost about twenty scalar
+            // instructions of flow bookkeeping per group; the compare chain is ordered by likelihood (a short overshoot first).
+            asm("s_cmp_lt_u32 %[k], 1\n\ts_cbranch_scc1 10f\n\t"
+                "s_cmp_lt_u32 %[k], 2\n\ts_cbranch_scc1 11f\n\t"
+                "s_cmp_lt_u32 %[k], 3\n\ts_cbranch_scc1 12f\n\t"
+                "s_cmp_lt_u32 %[k], 4\n\ts_cbranch_scc1 13f\n\t"
+                "v_mov_b32 %[r0], %[b4]\n\tv_mov_b32 %[r1], %[b5]\n\tv_mov_b32 %[r2], %[b6]\n\tv_mov_b32 %[r3], %[b7]\n\t"      // d = 16
+                "s_branch 19f\n"
+                "13:\n\t"
+                "v_alignbyte_b32 %[r0], %[b4], %[b3], %[sh]\n\tv_alignbyte_b32 %[r1], %[b5], %[b4], %[sh]\n\t"
+                "v_alignbyte_b32 %[r2], %[b6], %[b5], %[sh]\n\tv_alignbyte_b32 %[r3], %[b7], %[b6], %[sh]\n\t"
+                "s_branch 19f\n"
+                "12:\n\t"
+                "v_alignbyte_b32 %[r0], %[b3], %[b2], %[sh]\n\tv_alignbyte_b32 %[r1], %[b4], %[b3], %[sh]\n\t"
+                "v_alignbyte_b32 %[r2], %[b5], %[b4], %[sh]\n\tv_alignbyte_b32 %[r3], %[b6], %[b5], %[sh]\n\t"
+                "s_branch 19f\n"
+                "11:\n\t"
+                "v_alignbyte_b32 %[r0], %[b2], %[b1], %[sh]\n\tv_alignbyte_b32 %[r1], %[b3], %[b2], %[sh]\n\t"
+                "v_alignbyte_b32 %[r2], %[b4], %[b3], %[sh]\n\tv_alignbyte_b32 %[r3], %[b5], %[b4], %[sh]\n\t"
+                "s_branch 19f\n"
+                "10:\n\t"
+                "v_alignbyte_b32 %[r0], %[b1], %[b0], %[sh]\n\tv_alignbyte_b32 %[r1], %[b2], %[b1], %[sh]\n\t"
+                "v_alignbyte_b32 %[r2], %[b3], %[b2], %[sh]\n\tv_alignbyte_b32 %[r3], %[b4], %[b3], %[sh]\n"
+                "19:"
+                : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+                : [k] "s"(d >> 2), [sh] "s"(sh), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [b4] "v"(b4), [b5] "v"(b5),
+                  [b6] "v"(b6), [b7] "v"(b7)
+                : "scc");
             wnext = ((uint64_t)r1 << 32) | r0;
             wnext2 = ((uint64_t)r3 << 32) | r2;
         }
