@@ -106,14 +106,13 @@ __device__ __forceinline__ void ring_append64(bitring& r, uint64_t bits, uint32_
     const uint32_t o = r.bitpos + incl - nb;
     const uint32_t sh = o & 31;
     const uint32_t w = o >> 5;
-    if (nb) {
-        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
-        atomicOr(&r.ring[w & (ZZ_RING_WORDS - 1)], lo << sh);
-        if (sh + nb > 32) {
-            const uint32_t w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh);
-            atomicOr(&r.ring[(w + 1) & (ZZ_RING_WORDS - 1)], w1);
-            if (sh + nb > 64) atomicOr(&r.ring[(w + 2) & (ZZ_RING_WORDS - 1)], sh ? hi >> (32 - sh) : 0u);
-        }
+    {   // all three words every time (ORs with zero past the fragment's end): no lane-mask regions
+        const uint64_t b = nb ? bits : 0ull;
+        const uint64_t x = b << sh;
+        const uint32_t top = (uint32_t)(((b >> 32) << sh) >> 32);          // what the shift pushed out of 64 bits
+        atomicOr(&r.ring[w & (ZZ_RING_WORDS - 1)], (uint32_t)x);
+        atomicOr(&r.ring[(w + 1) & (ZZ_RING_WORDS - 1)], (uint32_t)(x >> 32));
+        atomicOr(&r.ring[(w + 2) & (ZZ_RING_WORDS - 1)], top);
     }
     r.bitpos += total;
     ring_flush_all_full(r);
@@ -928,26 +927,25 @@ __device__ __forceinline__ void l2_emit_records(bitring& ring, const uint16_t* r
         const uint64_t mbn = ballot(vn == ZZ_L2_REC_MATCH);
         uint32_t tn = 0;
         if (vn == ZZ_L2_REC_MATCH) tn = tokens[mc + mbcnt(mbn)];
-        uint64_t bits = 0; uint32_t nb = 0;
-        if (v < ZZ_L2_REC_MATCH) {
-            const uint32_t cd = codes[v];
-            bits = cd & 0xFFFF; nb = cd >> 16;
-        } else if (v == ZZ_L2_REC_MATCH) {
-            const uint32_t ls = t >> 23, lev = (t >> 18) & 31, bucket = (t >> 13) & 31, dev = t & 0x1FFF;
-            const uint32_t leb = (ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2;      // luts.cpp:64
-            const uint32_t deb = bucket < 4 ? 0 : (bucket - 2) >> 1;
-            const uint32_t lc = codes[257 + ls];
-            uint32_t ln = lc >> 16;
-            uint64_t w = (lc & 0xFFFF) | ((uint64_t)lev << ln);         // Merge, :121-124
-            ln += leb;
-            const uint32_t dc = dcodes[bucket];
-            w |= (uint64_t)(dc & 0xFFFF) << ln;                         // WriteDistance, :135-141
-            ln += dc >> 16;
-            w |= (uint64_t)dev << ln;
-            ln += deb;
-            bits = w; nb = ln;
-        }
-        ring_append64(ring, bits, nb);
+        // One straight line for literals, matches and the padding of the last trip (no lane-mask regions: with both kinds in
+        // nearly every trip both sides ran anyway, plus the scalar bookkeeping of two regions). A literal is a match whose
+        // token is 0: length symbol 0 -> no extra bits, distance part switched off.
+        const bool ism = v == ZZ_L2_REC_MATCH;
+        const uint32_t ls = t >> 23, lev = (t >> 18) & 31, bucket = (t >> 13) & 31, dev = t & 0x1FFF;   // (t = 0 unless a match)
+        const uint32_t leb = (ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2;          // luts.cpp:64
+        const uint32_t deb = bucket < 4 ? 0 : (bucket - 2) >> 1;
+        uint32_t lc = codes[ism ? 257 + ls : (v & 0x1FF)];
+        if (v > ZZ_L2_REC_MATCH) lc = 0;                                        // ZZ_L2_REC_NONE: nothing
+        uint32_t dc = dcodes[bucket];
+        if (!ism) dc = 0;
+        uint32_t ln = lc >> 16;
+        uint64_t w = (lc & 0xFFFF) | ((uint64_t)lev << ln);                     // Merge, :121-124
+        ln += leb;
+        w |= (uint64_t)(dc & 0xFFFF) << ln;                                     // WriteDistance, :135-141
+        ln += dc >> 16;
+        w |= (uint64_t)dev << ln;
+        ln += deb;
+        ring_append64(ring, w, ln);
         v = vn; vn = vnn; t = tn; mb = mbn;
     }
 }
@@ -969,11 +967,14 @@ __device__ __forceinline__ uint32_t l2_count_bits(const uint16_t* recs, const ui
         const uint64_t mbn = ballot(vn == ZZ_L2_REC_MATCH);
         uint32_t tn = 0;
         if (vn == ZZ_L2_REC_MATCH) tn = tokens[mc + mbcnt(mbn)];
-        if (v < ZZ_L2_REC_MATCH) acc += codes[v] >> 16;
-        else if (v == ZZ_L2_REC_MATCH) {
+        {   // (the same straight line as in l2_emit_records)
+            const bool ism = v == ZZ_L2_REC_MATCH;
             const uint32_t ls = t >> 23, bucket = (t >> 13) & 31;
-            acc += (codes[257 + ls] >> 16) + ((ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2) + (dcodes[bucket] >> 16) +
-                   (bucket < 4 ? 0 : (bucket - 2) >> 1);
+            uint32_t lc = codes[ism ? 257 + ls : (v & 0x1FF)];
+            if (v > ZZ_L2_REC_MATCH) lc = 0;
+            uint32_t dc = dcodes[bucket];
+            if (!ism) dc = 0;
+            acc += (lc >> 16) + ((ls < 8 || ls == 28) ? 0 : (ls - 4) >> 2) + (dc >> 16) + (bucket < 4 ? 0 : (bucket - 2) >> 1);
         }
         v = vn; vn = vnn; t = tn; mb = mbn;
     }
