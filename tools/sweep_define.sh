@@ -12,5 +12,5 @@ for v in "${VALS[@]}"; do
   lib=$R/gpurun_out/sweep/libzz_${M}_${v}.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -D${M}=${v} -o $lib $R/zzflate_amd/csrc/zz_api.hip $R/zzflate_amd/csrc/zz_cxx_shim.cpp
   echo "## ${M}=${v}"
-  ZZFLATE_AMD_LIB=$lib timeout -k 5 200 python $R/bench.py "$@" 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms'], d.get('level2',{}).get('value'))"
+  ZZFLATE_AMD_LIB=$lib timeout -k 5 200 python $R/bench.py "$@" 2>&1 | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["roofline"]["kernel_ms"], (d.get("level2") or {}).get("value"))'
 done

@@ -989,6 +989,9 @@ struct zz_l2_params {
 };
 
 #define ZZ_L2_THREADS (2 * ZZ_WAVE)
+#ifndef ZZ_L2_SPLIT64
+#define ZZ_L2_SPLIT64 39u      // 64ths of the records that wavefront 0 emits
+#endif
 // one wave's own memory traffic has landed (the code after the token pass runs on wavefront 0 alone: no s_barrier there)
 #define ZZ_WAVE_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 
@@ -1266,7 +1269,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
             // body: both wavefronts emit. This one takes the records [0, r1), the helper the rest and everything behind
             // them; the word the two parts share is put together by the helper at the end.
             {
-                const uint32_t r1 = ((nbody * 39u) >> 6) & ~63u;     // a little more than half: the helper also has a dry run to do
+                const uint32_t r1 = ((nbody * ZZ_L2_SPLIT64) >> 6) & ~63u;   // a little more than half: the helper also has a dry run to do
                 if (lane == 0) { share[0] = 2; share[1] = r1; share[2] = ring.bitpos; }
                 __syncthreads();             // (X)
                 l2_emit_records(ring, recs, tokens, codes, dcodes, 0, r1, 0);
