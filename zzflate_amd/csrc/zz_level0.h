@@ -45,19 +45,32 @@ __device__ __forceinline__ void coop_copy_adler(uint8_t* dst, const uint8_t* src
     const uint64_t body = (n - head) >> 4;
     const uint8_t* s = src + head;
     uint4* d4 = (uint4*)(dst + head);
-    for (uint64_t i = tid; i < body; i += nthreads) {
+    auto sums = [&](const uint4& v, uint64_t i) {
+        if (!want) return;
+        const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, 0u), s1 = __builtin_amdgcn_sad_u8(v.y, 0u, 0u);
+        const uint32_t s2 = __builtin_amdgcn_sad_u8(v.z, 0u, 0u), s3 = __builtin_amdgcn_sad_u8(v.w, 0u, 0u);
+        auto w3 = [](uint32_t x) { return ((x >> 8) & 0xFF) + 2 * ((x >> 16) & 0xFF) + 3 * (x >> 24); };
+        const uint32_t t = w3(v.x) + (w3(v.y) + 4 * s1) + (w3(v.z) + 8 * s2) + (w3(v.w) + 12 * s3);
+        const uint32_t sum = s0 + s1 + s2 + s3;
+        A += sum;
+        C += (uint64_t)(base + (uint32_t)head + (uint32_t)(i << 4)) * sum + t;
+    };
+    uint64_t i = tid;
+    // four independent 16-byte loads in flight per thread, then four aligned stores (as coop_copy does)
+    for (; i + 3 * (uint64_t)nthreads < body; i += 4 * (uint64_t)nthreads) {
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, s + (i << 4), 16);
+        __builtin_memcpy(&v1, s + ((i + nthreads) << 4), 16);
+        __builtin_memcpy(&v2, s + ((i + 2 * (uint64_t)nthreads) << 4), 16);
+        __builtin_memcpy(&v3, s + ((i + 3 * (uint64_t)nthreads) << 4), 16);
+        d4[i] = v0; d4[i + nthreads] = v1; d4[i + 2 * (uint64_t)nthreads] = v2; d4[i + 3 * (uint64_t)nthreads] = v3;
+        sums(v0, i); sums(v1, i + nthreads); sums(v2, i + 2 * (uint64_t)nthreads); sums(v3, i + 3 * (uint64_t)nthreads);
+    }
+    for (; i < body; i += nthreads) {
         uint4 v;
         __builtin_memcpy(&v, s + (i << 4), 16);
         d4[i] = v;
-        if (want) {
-            const uint32_t s0 = __builtin_amdgcn_sad_u8(v.x, 0u, 0u), s1 = __builtin_amdgcn_sad_u8(v.y, 0u, 0u);
-            const uint32_t s2 = __builtin_amdgcn_sad_u8(v.z, 0u, 0u), s3 = __builtin_amdgcn_sad_u8(v.w, 0u, 0u);
-            auto w3 = [](uint32_t x) { return ((x >> 8) & 0xFF) + 2 * ((x >> 16) & 0xFF) + 3 * (x >> 24); };
-            const uint32_t t = w3(v.x) + (w3(v.y) + 4 * s1) + (w3(v.z) + 8 * s2) + (w3(v.w) + 12 * s3);
-            const uint32_t sum = s0 + s1 + s2 + s3;
-            A += sum;
-            C += (uint64_t)(base + (uint32_t)head + (uint32_t)(i << 4)) * sum + t;
-        }
+        sums(v, i);
     }
     const uint64_t done = head + (body << 4);
     const uint64_t tail = n - done;
