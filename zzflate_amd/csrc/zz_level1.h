@@ -410,7 +410,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             const uint64_t wq = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w);
             const uint64_t wq2 = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w2 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w2);
             const uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
-            const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | ((uint32_t)__builtin_popcountll(myset) > 2u ? ZZ_WI_HARD : 0u)   // ... shared by more than two lanes
+            const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | ((uint32_t)__builtin_popcountll(below) > 1u ? ZZ_WI_HARD : 0u)   // two or more earlier lanes share my hash: which of them the parse visited decides
                                 | (lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT));
             info = dup ? di : 0u;
         }
