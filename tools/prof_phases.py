@@ -44,8 +44,9 @@ if level >= 2:
     sys.exit(0)
 names = ["loop top", "hash+probe issue", "emit prev group", "readback+dup loop", "wait cand load", "info VALU", "walk", "repair+pack", "wait wnext"]
 tot = sum(prof[:9])
-print(f"input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; groups {prof[10]}, events {prof[11]}, simple events {prof[12]}")
-print(f"complex events/group: hard {prof[12]/max(1,prof[10]):.3f} dup {prof[13]/max(1,prof[10]):.3f} ext-only {prof[14]/max(1,prof[10]):.3f}; dup sets/group {prof[15]/max(1,prof[10]):.3f}")
-print(f"bytes/group {n / max(1, prof[10]):.1f}, events/group {prof[11] / max(1, prof[10]):.2f}, cycles/group {tot / max(1, prof[10]):.0f}")
+g = max(1, prof[10])
+print(f"input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; groups {prof[10]}")
+print(f"per group: event lanes {prof[12]/g:.2f} (with an in-group candidate {prof[15]/g:.2f}); walk left for the C++ path {prof[11]/g:.3f} times (hard {prof[13]/g:.3f}, 16-or-more {prof[14]/g:.3f})")
+print(f"bytes/group {n / g:.1f}, cycles/group {tot / g:.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:16s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):8.0f} cyc/group")

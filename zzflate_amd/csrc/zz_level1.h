@@ -435,6 +435,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         }
 
         ZZ_T(5); ZZ_C(10, 1);
+        ZZ_C(11 + 4, (uint32_t)__builtin_popcountll(ballot((info & ZZ_WI_DUP) != 0) & E));   // (diagnostic) event lanes with an in-group candidate
+        ZZ_C(11 + 1, (uint32_t)__builtin_popcountll(E));                                        // (diagnostic) event lanes
         // (3) the walk: replays the reference's decisions in order (encoder.cpp:341-368). Scalar code is slow
         // on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip), so runs
         // of "simple" matches go through a hand-written 12-instruction loop; everything else drops out to C++.
@@ -448,7 +450,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             ZZ_C(11, 1);
             const uint64_t probed = ~cov | mst;                         // lanes below e the parse has visited
             const uint32_t inf = readlane(info, e);
-            ZZ_C(12, (inf & ZZ_WI_HARD) ? 1 : 0); ZZ_C(13, (inf & ZZ_WI_DUP) ? 1 : 0); ZZ_C(14, (!(inf & ZZ_WI_DUP) && (inf & ZZ_WI_EXTA)) ? 1 : 0);
+            ZZ_C(13, (inf & ZZ_WI_HARD) ? 1 : 0); ZZ_C(14, (!(inf & ZZ_WI_DUP) && (inf & ZZ_WI_EXTA)) ? 1 : 0);
             const uint32_t pe = cur + (uint32_t)e;
             const uint32_t maxlen = (n - pe) < ZZ_MAX_LEN ? (n - pe) : ZZ_MAX_LEN;
             uint32_t mlen;
