@@ -638,22 +638,62 @@ static int64_t first_pass(enc_t* e, const uint8_t* src, int64_t startPos, int64_
     return end;
 }
 
-/* encoder.cpp:217-303 WriteBlock2Pass */
-static int64_t block_dynamic(enc_t* e, const uint8_t* src, int64_t byteCount, int final)
+/* ---- optimal length-limited code lengths by package-merge -- NOT in the reference (its limiter is the frequency
+ * floor above, huffman.cpp:122-154); used by the extended levels 4..6 only. Larmore/Hirschberg 1990 in
+ * the list form: the symbols with a non-zero count, sorted by (count, symbol), are the leaves; list 1 is the leaves;
+ * list l+1 is the merge of the leaves with the packages of list l (consecutive pairs, weights added; an unpaired last
+ * item is dropped), a leaf going first where weights are equal; of the last list (l = maxlen) the first 2m-2 items
+ * are taken, of every earlier list twice as many items as packages were taken from its successor; a symbol's length
+ * is the number of lists in which its leaf is among the items taken. Since every list holds the leaves in the same
+ * order, "the leaves taken from list l" is a count a_l, and the symbol of sorted rank r gets length #{l : r < a_l}.
+ * This is also the product's formulation (zz_level6.h), so ties are decided identically. ---------------------------- */
+static void pm_lengths(const int* freqs, int n, int maxlen, int* out)
 {
-    int nrec = 0;
-    e->ntok = 0;
-    int64_t target = byteCount - MAX_LEN > 0 ? byteCount - MAX_LEN : 0; /* :222 */
-    int64_t length = 0;
-    while (target > 0 && nrec < MAX_RECORDS) {               /* :225-234 */
-        int64_t batch = target < BATCH_LEN ? target : BATCH_LEN;
-        int64_t newEnd = first_pass(e, src, length, length + batch, &nrec);
-        target -= newEnd - length;
-        length = newEnd;
+    int sym[288]; int64_t w[288];
+    int m = 0;
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    for (int i = 0; i < n; ++i) if (freqs[i] != 0) { sym[m] = i; w[m] = freqs[i]; m++; }
+    if (m == 0) return;
+    if (m == 1) { out[sym[0]] = 1; return; }
+    for (int i = 1; i < m; ++i) {                           /* insertion sort by (count, symbol): stable on the symbol order */
+        int s0 = sym[i]; int64_t w0 = w[i]; int j = i;
+        while (j > 0 && w[j - 1] > w0) { sym[j] = sym[j - 1]; w[j] = w[j - 1]; j--; }
+        sym[j] = s0; w[j] = w0;
     }
-    if (target <= 0 && nrec < MAX_RECORDS) { nrec++; length = byteCount; } /* :236-245 */
-    fix_hash(e, length);                                     /* :248 */
+    /* isleaf[l][k]: item k of list l+1 is a leaf. Lists are cut at 2m-2 items: nothing behind that is ever taken. */
+    static _Thread_local uint8_t isleaf[16][2 * 288];
+    int64_t cur[2 * 288], nxt[2 * 288];
+    int ncur = m, lim = 2 * m - 2;
+    int lens_l[16];
+    for (int k = 0; k < m; ++k) { cur[k] = w[k]; isleaf[0][k] = 1; }
+    lens_l[0] = m;
+    for (int l = 1; l < maxlen; ++l) {
+        int np = ncur / 2, a = 0, b = 0, k = 0;
+        while (k < lim && (a < m || b < np)) {
+            int64_t pw = b < np ? cur[2 * b] + cur[2 * b + 1] : 0;
+            if (a < m && (b >= np || w[a] <= pw)) { nxt[k] = w[a++]; isleaf[l][k] = 1; }
+            else { nxt[k] = pw; isleaf[l][k] = 0; b++; }
+            k++;
+        }
+        memcpy(cur, nxt, sizeof(int64_t) * (size_t)k);
+        ncur = k; lens_l[l] = k;
+    }
+    int need = lim;
+    for (int l = maxlen - 1; l >= 0; --l) {
+        if (need > lens_l[l]) need = lens_l[l];
+        int a = 0;
+        for (int k = 0; k < need; ++k) a += isleaf[l][k];
+        for (int r = 0; r < a; ++r) out[sym[r]]++;
+        need = 2 * (need - a);
+    }
+}
 
+/* The back half of WriteBlock2Pass (encoder.cpp:253-303): histograms over the tokens, code construction, exact size,
+ * stored fallback or dynamic header + body. `pm`: code lengths by package-merge (extended levels) instead of the
+ * reference's CalcLengths. */
+static int64_t emit_dynamic(enc_t* e, const uint8_t* src, int64_t length, int64_t byteCount, int final, int pm)
+{
+    void (*calc)(const int*, int, int, int*) = pm ? pm_lengths : zzo_calc_lengths;
     /* :253 + :442-471 GetFrequencies, by position */
     int symF[286] = { 0 }, distF[30] = { 0 };
     {
@@ -674,16 +714,16 @@ static int64_t block_dynamic(enc_t* e, const uint8_t* src, int64_t byteCount, in
     memset(codes, 0, sizeof codes); memset(dcodes, 0, sizeof dcodes); memset(meta, 0, sizeof meta);
     lrec_t symRecs[320], distRecs[64];
     int64_t bits = 0;
-    zzo_calc_lengths(symF, 286, 15, lens);
+    calc(symF, 286, 15, lens);
     generate_codes(lens, 286, codes);
     int nSymRecs = from_lengths(lens, 286, metaF, symRecs);
     for (int i = 0; i < 286; ++i) bits += (int64_t)symF[i] * (lens[i] + g_sym_extra_bits[i]);
-    zzo_calc_lengths(distF, 30, 15, lens);
+    calc(distF, 30, 15, lens);
     generate_codes(lens, 30, dcodes);
     int nDistRecs = from_lengths(lens, 30, metaF, distRecs);
     for (int i = 0; i < 30; ++i) bits += (int64_t)distF[i] * (lens[i] + g_dist_extra[i]);
     int metaLens[19];
-    zzo_calc_lengths(metaF, 19, 7, metaLens);
+    calc(metaF, 19, 7, metaLens);
     generate_codes(metaLens, 19, meta);
     /* :267-271 exact size */
     int64_t total = 3 + 5 + 5 + 4 + 3 * 19 + bits;
@@ -716,11 +756,99 @@ static int64_t block_dynamic(enc_t* e, const uint8_t* src, int64_t byteCount, in
     return length;
 }
 
+/* encoder.cpp:217-303 WriteBlock2Pass */
+static int64_t block_dynamic(enc_t* e, const uint8_t* src, int64_t byteCount, int final)
+{
+    int nrec = 0;
+    e->ntok = 0;
+    int64_t target = byteCount - MAX_LEN > 0 ? byteCount - MAX_LEN : 0; /* :222 */
+    int64_t length = 0;
+    while (target > 0 && nrec < MAX_RECORDS) {               /* :225-234 */
+        int64_t batch = target < BATCH_LEN ? target : BATCH_LEN;
+        int64_t newEnd = first_pass(e, src, length, length + batch, &nrec);
+        target -= newEnd - length;
+        length = newEnd;
+    }
+    if (target <= 0 && nrec < MAX_RECORDS) { nrec++; length = byteCount; } /* :236-245 */
+    fix_hash(e, length);                                     /* :248 */
+    return emit_dynamic(e, src, length, byteCount, final, 0);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Extended levels 4, 5, 6 -- NOT in the reference, which has one slot per hash, no chains, no lazy
+ * matching, and rejects level > 3 (encoder.h:41-43,76; encoder.cpp:388-424; zzflate.cpp:201,230-234).
+ * SURVEY.md 8f.2 defines the extension: bounded hash chains, lazy matching, package-merge code lengths.
+ * This is the executable definition the product's levels 4..6 are tested against (packet mode only):
+ *
+ *   window   the last min(bytes in front of the packet, X.window) bytes in front of the packet may be matched;
+ *   chains   every position q in [-window, target), target = n - 16 (so that the 16 bytes counted at a position lie
+ *            inside the data; the reference's level 2 stops 258 short, encoder.cpp:222), is entered under a 13-bit
+ *            hash of its FOUR bytes (x_hash4; the reference hashes three, encoder.cpp:11-17: four-byte keys waste
+ *            far fewer chain entries on collisions), ascending; prev(q) = the nearest earlier entered position with
+ *            the same hash;
+ *   match    for q in [0, target): candidates prev(q), prev(prev(q)), ... -- at most X.depth of them, while the
+ *            distance stays below 32768; a candidate's length is the common prefix with q, counted up to X_CAP = 16
+ *            bytes; the longest wins, the nearer one among equals. It is a match if that length is >= 4;
+ *   lazy     position q defers (stays a literal) if it has a match shorter than X_CAP and q+1 has a longer one
+ *            (counted the same way) -- except where (q & 63) == 63 (the product works in groups of 64 positions);
+ *   parse    greedy over the positions that have a match and do not defer; a match that reached X_CAP bytes is
+ *            extended against its candidate up to 258 bytes (and the end of the data); nothing else depends on
+ *            the parse, which is what lets the product find all matches in parallel;
+ *   block    one dynamic block per packet as at level 2 (encoder.cpp:253-303: stored fallback, 286/30/19 header),
+ *            code lengths by package-merge.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int depth; int window; } xlevel_t;
+enum { X_CAP = 16, X_TAIL = 16 };
+static const xlevel_t g_xlevels[3] = { { 2, 8192 }, { 4, 32768 }, { 8, 32768 } };   /* levels 4, 5, 6 */
+static inline uint32_t x_hash4(const enc_t* e, const uint8_t* p)      /* 13 bits of the FOUR bytes at p (Knuth's multiplier) */
+{
+    return ((uint32_t)load_le(e, p, 4) * 2654435761u) >> (32 - HASH_BITS);
+}
+static int64_t block_extended(enc_t* e, const uint8_t* src, int64_t n, int final, int64_t before)
+{
+    const xlevel_t X = g_xlevels[e->level - 4];
+    const int64_t W = before < X.window ? before : X.window;
+    const int64_t target = n - X_TAIL > 0 ? n - X_TAIL : 0;
+    int32_t* prev = (int32_t*)malloc(sizeof(int32_t) * (size_t)(W + target + 1));
+    uint8_t* L = (uint8_t*)calloc((size_t)target + 2, 1);
+    uint16_t* Dd = (uint16_t*)calloc((size_t)target + 2, 2);
+    const int32_t NONE = INT32_MIN;
+    int32_t head[HASH_SIZE];
+    for (int i = 0; i < HASH_SIZE; ++i) head[i] = NONE;
+    for (int64_t q = -W; q < target; ++q) {                  /* chains: every position, ascending */
+        uint32_t h = x_hash4(e, src + q);
+        prev[q + W] = head[h];
+        head[h] = (int32_t)q;
+    }
+    for (int64_t q = 0; q < target; ++q) {                   /* best of the chain, lengths counted up to X_CAP */
+        int best = 0; int64_t bdist = 0;
+        int32_t c = prev[q + W];
+        for (int k = 0; k < X.depth && c != NONE && q - c < MAX_DIST; ++k, c = prev[c + W]) {
+            int len = match_forward(e, src + q, src + c, X_CAP);    /* (q + X_CAP <= n: nothing to clamp) */
+            if (len > best) { best = len; bdist = q - c; }
+        }
+        if (best >= 4) { L[q] = (uint8_t)best; Dd[q] = (uint16_t)bdist; }
+    }
+    e->ntok = 0;
+    for (int64_t p = 0; p < target;) {                       /* greedy parse with one-step lazy evaluation */
+        int len = L[p];
+        const int defer = len && len < X_CAP && (p & 63) != 63 && L[p + 1] > len;   /* (L[target] = 0) */
+        if (!len || defer) { p++; continue; }
+        if (len == X_CAP) len = match_forward(e, src + p, src + p - Dd[p], n - p < MAX_LEN ? (int)(n - p) : MAX_LEN);
+        push_token(e, p, Dd[p], len);
+        p += len;
+    }
+    free(prev); free(L); free(Dd);
+    return emit_dynamic(e, src, n, n, final, 1);
+}
+void zzo_pm_lengths(const int* freqs, int n, int maxlen, int* out) { pm_lengths(freqs, n, maxlen, out); }
+
 /* encoder.cpp:506-527 WriteDeflateBlock */
 static int64_t write_block(enc_t* e, const uint8_t* src, int64_t len, int final)
 {
     if (e->level == 0) return block_stored(e, src, len, final);
     if (e->level == 1) return block_fixed(e, src, len, final);
+    if (e->level >= 4) return block_extended(e, src, len, final, src - e->gbase);   /* (packet mode only: len <= 32768) */
     if (len > 500000) { len = 500000; final = 0; }           /* :518-522 */
     return block_dynamic(e, src, len, final);
 }
@@ -888,12 +1016,12 @@ uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t 
     const uint8_t* end = s + len;
     if (is_final) {
         enc_init(e, level, out, cap, 1, base, end);
-        if (warm && level >= 1) prehash(e, s, off, warm);
+        if (warm && level >= 1 && level <= 3) prehash(e, s, off, warm);
         add_data(e, s, end, 1);                              /* :110-113 */
     } else {
         enc_init(e, level, out, cap, 1, base, end - (len ? 1 : 0));
         if (len) {
-            if (warm && level >= 1) prehash(e, s, off, warm);
+            if (warm && level >= 1 && level <= 3) prehash(e, s, off, warm);
             add_data(e, s, end - 1, 0);                      /* :116 */
             e->level = 0;                                    /* :119 SetLevel(0) */
             e->gend = end;
@@ -917,7 +1045,7 @@ uint64_t zzo_encode_packets_warm(uint8_t* dest, uint64_t cap, const uint8_t* src
 {
     uint8_t h[10];
     int hl = header_bytes(format, h);
-    if (level < 0 || level > 3 || cap < (uint64_t)hl || packet_size == 0) return ZZO_ERROR;
+    if (level < 0 || level > 6 || cap < (uint64_t)hl || packet_size == 0) return ZZO_ERROR;   /* 4..6: the extended levels */
     memcpy(dest, h, (size_t)hl);
     uint64_t count = (uint64_t)hl;
     uint64_t npk = (n + packet_size - 1) / packet_size;       /* fixed-size ranges replace :67-78,:97-99 */

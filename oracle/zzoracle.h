@@ -48,6 +48,12 @@ uint64_t zzo_encode_packets_warm(uint8_t* dest, uint64_t cap, const uint8_t* src
 uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t len, int is_final,
                          uint8_t* out, uint64_t cap, uint64_t warm);
 
+/* Extended levels 4, 5, 6 (NOT in the reference, which rejects level > 3: zzflate.cpp:201,230-234): bounded
+ * hash chains (depth 2 / 4 / 8) over a window of 8 / 32 / 32 KiB in front of the packet, one-step lazy matching,
+ * package-merge code lengths. Packet mode only: pass level 4..6 to zzo_encode_packets / zzo_packet (warm is ignored
+ * there: the levels bring their own window). The definition is in zzoracle.c ("Extended levels"). */
+void zzo_pm_lengths(const int* freqs, int n, int maxlen, int* out);             /* optimal length-limited code lengths */
+
 /* checksums */
 uint32_t zzo_adler32(uint32_t start, const uint8_t* p, uint64_t n);             /* adler.cpp:17-43  */
 uint32_t zzo_adler_combine(uint32_t first, uint32_t second, uint64_t len2);    /* adler.cpp:5-15   */
