@@ -28,7 +28,6 @@ import ctypes
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,102 +38,93 @@ SEEDS = {"text": 0x5EED0002, "random": 0x5EED0003, "mix": 0x5EED0004, "log": 0x5
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def effective_cores():
+    """Cores this process may really use: the scheduler affinity mask, cut down by the cgroup CPU quota when there is one
+    (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us). Returns (cores, affinity, quota or None)."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return cores, affinity, quota
+
+
 def cpu_baseline(sample: bytes, level: int, fmt: int, P: int = 32768):
-    """Time the reference's CPU encoder on this box's host cores, one thread per core, each on its own 32 MiB slices of
-    the sample, in two forms:
-      * whole-slice: one ZzFlateEncode(threaded=false) call per slice -- the reference as its own callers run it;
+    """Time the reference's CPU encoder on this box's host cores, in two forms:
+      * whole-slice: one ZzFlateEncode(threaded=false) call per 16 MiB slice -- the reference as its own callers run it;
       * packet mode: the packet recipe (zzflate.cpp:101-125) over the same P-byte ranges the GPU uses -- the same work
         as the GPU's, and the same bytes: its ratio must equal the GPU line's.
-    Returns the cpu_baseline JSON object (`value` = whole-slice GB/s, `packet_mode` = the second form)."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    Each form is timed on ONE thread first and then on every core the process may use (affinity cut down by the cgroup
+    quota), by a native driver (oracle/ref_harness.cpp zzref_bench: native threads, static partition, per-thread output
+    buffers; no Python in the loop), so that `value / cores` can be held against the one-thread rate.
+    Returns the cpu_baseline JSON object (`value` = whole-slice GB/s on all cores, `packet_mode` = the second form)."""
+    cores, affinity, quota = effective_cores()
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libzzref.so")
-    slice_bytes = 32 << 20
+    slice_bytes = 16 << 20
     nslices = max(1, len(sample) // slice_bytes)
-    rounds = max(1, (4 * cores) // nslices)   # every core gets ~4 slices => ~15-25 s of CPU work in total
-    u64, u32, ci, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
+    u64, u32, ci, vp, dbl = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
     if os.path.exists(ref_path):
-        L = ctypes.CDLL(ref_path)
-        fn = L.zzref_encode_inplace
-        fn.restype = u64
-        fn.argtypes = [vp, u64, vp, u64, ci, ci, ci]
-        pk = L.zzref_packet
-        pk.restype = u64
-        pk.argtypes = [ci, vp, u64, u64, ci, vp, u64, u32]
+        fn = ctypes.CDLL(ref_path).zzref_bench
         kind = "reference"
-
-        def run(dst, cap, at, n, first, last):
-            return fn(dst, cap, base + at, n, fmt, level, 0)
-
-        def run_packets(dst, cap, at, n, first, last):
-            # raw DEFLATE of the packets of this slice (offsets from the start of the sample: level >= 2 extends matches
-            # backward into the bytes in front of a packet); only the very last packet of the sample is final
-            tot = 0
-            for off in range(at, at + n, P):
-                ln = min(P, at + n - off)
-                tot += pk(level, base, off, ln, 1 if (last and off + ln == at + n) else 0, dst, cap, 1)
-            return tot
     else:
         import subprocess
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-        L = ctypes.CDLL(os.path.join(ROOT, "oracle", "libzzoracle.so"))
-        fn = L.zzo_encode
-        fn.restype = u64
-        fn.argtypes = [vp, u64, vp, u64, ci, ci]
-        pk = L.zzo_packet
-        pk.restype = u64
-        pk.argtypes = [ci, vp, u64, u64, ci, vp, u64]
+        fn = ctypes.CDLL(os.path.join(ROOT, "oracle", "libzzoracle.so")).zzo_bench
         kind = "port"
-
-        def run(dst, cap, at, n, first, last):
-            return fn(dst, cap, base + at, n, fmt, level)
-
-        def run_packets(dst, cap, at, n, first, last):
-            tot = 0
-            for off in range(at, at + n, P):
-                ln = min(P, at + n - off)
-                tot += pk(level, base, off, ln, 1 if (last and off + ln == at + n) else 0, dst, cap)
-            return tot
+    fn.restype = dbl
+    fn.argtypes = [ci, vp, u64, u64, u64, ci, ci, ci, u32, ctypes.POINTER(u64), ctypes.POINTER(dbl)]
     buf = ctypes.create_string_buffer(sample, len(sample) + 64)   # >= 8 readable bytes after the data
     base = ctypes.addressof(buf)
-    nthreads = min(cores, nslices * rounds)
-    outs = [ctypes.create_string_buffer(2 * slice_bytes + 1024) for _ in range(nthreads)]
-
-    def timed(fn_slice, reps):
-        todo = list(range(nslices)) * reps
-        lock = threading.Lock()
-        produced = [0] * nslices
-
-        def worker(w):
-            while True:
-                with lock:
-                    if not todo:
-                        return
-                    sl = todo.pop()
-                r = fn_slice(outs[w], 2 * slice_bytes + 1024, sl * slice_bytes, slice_bytes, sl == 0, sl == nslices - 1)
-                produced[sl] = r
-        t0 = time.perf_counter()
-        ths = [threading.Thread(target=worker, args=(w,)) for w in range(nthreads)]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        dt = time.perf_counter() - t0
-        return nslices * reps * slice_bytes / dt / 1e9, sum(produced), dt
-
     total_in = nslices * slice_bytes
-    gbs, out_bytes, dt = timed(run, rounds)
     hl, tl = {0: (2, 4), 1: (10, 8), 2: (0, 0)}[fmt]
-    pgbs, pout, pdt = timed(run_packets, rounds)
-    return {
-        "value": round(gbs, 4), "unit": "GB/s", "cores": nthreads, "kind": kind,
-        "sample": f"{nslices * rounds} x {slice_bytes >> 20} MiB slices ({nslices} distinct) of the same input, level {level}, one "
-                  f"ZzFlateEncode(threaded=false) call per slice, one thread per core; ratio {out_bytes / total_in:.4f}; "
-                  f"{dt:.2f} s wall",
-        "packet_mode": {
-            "value": round(pgbs, 4), "unit": "GB/s", "cores": nthreads, "kind": kind,
-            "ratio": round((pout + hl + tl) / total_in, 4),
-            "sample": f"the same slices as {P}-byte packets (the recipe of zzflate.cpp:101-125, one Encoder per packet): the GPU's "
-                      f"work and the GPU's bytes; {pdt:.2f} s wall",
-        },
-    }
+
+    def run(mode, threads, nitems):
+        produced = (u64 * nslices)()
+        secs = (dbl * threads)()
+        wall = fn(mode, base, nslices, slice_bytes, nitems, threads, fmt, level, P, produced, secs)
+        return nitems * slice_bytes / wall / 1e9, wall, list(produced), list(secs)
+
+    out = {}
+    for mode, name in ((0, "whole"), (1, "packets")):
+        # one thread: ~4 slices (0.3-0.6 s at level 1); all cores: every slice at least once, every thread ~6 slices
+        # (~1 s of work each at level 1, more at level 2): the whole leg stays within ~10-30 s
+        one, one_wall, _, _ = run(mode, 1, min(4, nslices))
+        per_thread = 6
+        nitems = max(nslices, per_thread * cores)
+        allv, wall, produced, secs = run(mode, cores, nitems)
+        eff = (allv / cores) / one if one > 0 else None
+        out[name] = {
+            "value": round(allv, 4), "unit": "GB/s", "cores": cores, "kind": kind,
+            "one_thread": round(one, 4), "per_core": round(allv / cores, 4),
+            "scaling_efficiency": round(eff, 3) if eff is not None else None,
+            "scaling_flag": ("per-core rate is less than half the one-thread rate: memory bandwidth, SMT siblings or a CPU "
+                             "quota the affinity mask does not show; effective cores = value / one_thread = "
+                             f"{allv / one:.1f}") if (eff is not None and eff < 0.5) else None,
+            "thread_seconds_min_max": [round(min(secs), 2), round(max(secs), 2)], "wall_seconds": round(wall, 2),
+            "ratio": round((sum(produced) + (hl + tl if mode else 0)) / total_in, 4),
+            "items": nitems,
+        }
+    res = dict(out["whole"])
+    res["affinity_cores"] = affinity
+    res["cgroup_cpu_quota"] = quota
+    res["sample"] = (f"{out['whole']['items']} x {slice_bytes >> 20} MiB slices ({nslices} distinct) of the same input, level {level}, "
+                     f"one ZzFlateEncode(threaded=false) call per slice, native threads with a static partition "
+                     f"(oracle/ref_harness.cpp zzref_bench), {cores} threads; one thread alone on {min(4, nslices)} slices first")
+    pk = out["packets"]
+    pk["sample"] = (f"the same slices as {P}-byte packets (the recipe of zzflate.cpp:101-125, one Encoder per packet): the GPU's "
+                    f"work and the GPU's bytes")
+    res["packet_mode"] = pk
+    return res
 
 
 def launch_ranks(n):

@@ -18,7 +18,9 @@
  * fixed-size ranges ("packets", default 32 KiB) instead of hardware_concurrency() ranges; every packet is
  * bit-identical to the reference's packet recipe (zzflate.cpp:101-125) wherever that recipe yields a valid
  * DEFLATE encoding, and always valid otherwise. `threaded == 0` asks for the reference's single Encoder over the
- * whole input (zzflate.cpp:84-95): produced on the device too and bit-identical to the reference, including what
+ * whole input (zzflate.cpp:84-95): produced on the device too and bit-identical to the reference wherever the
+ * reference's stream is a valid encoding of the input (its multi-block level-1 stream is not when a short match crosses a
+ * block cut -- defect D12 in DESIGN.md: lengths stop at the block end here), including what
  * depends on where the output goes -- at level 1 the block lengths follow from the room in the caller's buffer
  * (encoder.cpp:331-337; zztest/Test.cpp passes dest = input size) or, through the callback, from the library's
  * 1,000,000-byte chunks (outputbitstream.h:171-201), and the callback receives exactly the reference's chunks. At
@@ -145,6 +147,23 @@ int zz_encode_stream_chunks_device(zz_ctx* ctx, const void* d_src, uint64_t n, v
 int zz_encode_shard_device(zz_ctx* ctx, const void* d_src, uint64_t n, uint64_t halo, int is_last_shard,
                            void* d_dst, uint64_t cap, uint64_t* out_len, uint32_t* cks, int checksum,
                            int level, uint32_t packet_size, void* hip_stream);
+
+/* The shard call in two halves (as zz_encode_device_async / zz_encode_finish), for ranks that enqueue the next step's shard
+ * before the previous one's size and checksum have been exchanged. */
+int zz_encode_shard_device_async(zz_ctx* ctx, const void* d_src, uint64_t n, uint64_t halo, int is_last_shard, void* d_dst,
+                                 uint64_t cap, int checksum, int level, uint32_t packet_size, void* hip_stream);
+int zz_encode_shard_finish(zz_ctx* ctx, uint64_t* out_len, uint32_t* cks, int checksum);
+
+/* Fan-out and join over several GPUs of ONE process, for data already resident on them -- WriteDeflateStream's
+ * std::async fan-out and in-order memmove join (zzflate.cpp:97-155) with devices for threads and xGMI peer copies for
+ * memmove; no torch, no RCCL. Shard i = d_src[i][0, n[i]) lives on the device of ctxs[i] (one context per shard; a device
+ * may appear more than once); the shards are consecutive ranges of one stream, every one but the last a whole number of
+ * packets; halo[i] (halo may be NULL = all 0) = readable bytes of the stream in front of d_src[i] on that device, as
+ * zz_encode_shard_device wants them. All shards are encoded concurrently; each is pulled to its final offset in d_dst --
+ * on the device of ctxs[0], where shard 0 is encoded in place -- with hipMemcpyPeerAsync as soon as the shards in front of
+ * it have finished; checksums are folded on the host; header and trailer are written. *out_len = bytes or ~0. */
+int zz_encode_multi_device(zz_ctx* const* ctxs, int nshards, const void* const* d_src, const uint64_t* n, const uint64_t* halo,
+                           void* d_dst, uint64_t cap, uint64_t* out_len, int format, int level, uint32_t packet_size);
 
 /* Self-verification: inflates, on the device, every packet of the stream the LAST zz_encode_device /
  * zz_encode_shard_device call on this context produced, and compares with that call's input (both buffers must still

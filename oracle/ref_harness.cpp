@@ -11,8 +11,11 @@
 // Harness rules for packets come from SURVEY.md section 8c (isolation + guard bytes for level 1,
 // real preceding bytes for level >= 2, one guard byte before packet 0).
 
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include <memory>
 
@@ -134,6 +137,48 @@ uint64_t zzref_encode_inplace(uint8_t* dest, uint64_t cap, const uint8_t* src, u
     size_t len = cap;
     ZzFlateEncode(dest, &len, src, n, &cfg);
     return len;
+}
+
+// ---- timing driver for bench.py's cpu_baseline leg -----------------------------------------------------------
+// Runs the reference over `nitems` work items on `threads` native threads and returns the wall time in seconds. Item j is
+// slice (j mod nslices) of base (slices of slice_bytes bytes) and belongs to thread j mod threads: a static partition,
+// no lock, no interpreter in the loop. Every thread allocates (and so first-touches) its own output buffer.
+//   mode 0: one ZzFlateEncode(threaded=false) call per slice -- the reference as its own callers run it (zztest/Test.cpp:161);
+//   mode 1: the packet recipe (zzflate.cpp:101-125) over the slice's P-byte ranges -- the GPU's work and the GPU's bytes;
+//           only the very last packet of the last slice is final.
+// produced[s] = output bytes of slice s (as last computed), thread_secs[t] = busy time of thread t.
+double zzref_bench(int mode, const uint8_t* base, uint64_t nslices, uint64_t slice_bytes, uint64_t nitems, int threads,
+                   int format, int level, uint32_t P, uint64_t* produced, double* thread_secs)
+{
+    using clk = std::chrono::steady_clock;
+    if (threads < 1) threads = 1;
+    const uint64_t cap = 2 * slice_bytes + 4096;
+    std::atomic<int> ready(0), go(0);
+    clk::time_point w0;
+    auto work = [&](int t) {
+        std::vector<uint8_t> out(cap, 1);                    // allocated and touched before the clock starts
+        ready.fetch_add(1);
+        if (t == 0) { while (ready.load() < threads) std::this_thread::yield(); w0 = clk::now(); go.store(1); }
+        else while (!go.load()) std::this_thread::yield();
+        const auto t0 = clk::now();
+        for (uint64_t j = (uint64_t)t; j < nitems; j += (uint64_t)threads) {
+            const uint64_t sl = j % nslices, at = sl * slice_bytes;
+            uint64_t r = 0;
+            if (mode == 0) r = zzref_encode_inplace(out.data(), cap, base + at, slice_bytes, format, level, 0);
+            else
+                for (uint64_t off = at; off < at + slice_bytes; off += P) {
+                    const uint64_t ln = at + slice_bytes - off < P ? at + slice_bytes - off : P;
+                    r += zzref_packet(level, base, off, ln, (sl == nslices - 1 && off + ln == at + slice_bytes) ? 1 : 0, out.data(), cap, 1);
+                }
+            produced[sl] = r;
+        }
+        thread_secs[t] = std::chrono::duration<double>(clk::now() - t0).count();
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    return std::chrono::duration<double>(clk::now() - w0).count();
 }
 
 // ---- checksums (adler.cpp:5-43, crc.cpp:24-33) ---------------------------------------------------

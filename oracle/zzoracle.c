@@ -26,9 +26,12 @@
  * Parity pinned: tests/test_oracle_vs_ref.py (against oracle/_ref, the compiled reference) and
  * tests/test_oracle_golden.py (against committed hashes of the reference's outputs).
  */
+#define _POSIX_C_SOURCE 200809L
 #include "zzoracle.h"
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------------------------------------
  * Constant tables, generated at first use from RFC 1951 3.2.5 (luts.cpp:5-110 hold the same data)
@@ -1080,4 +1083,58 @@ uint64_t zzo_bitstream(const uint64_t* bits, const int* counts, int n, uint8_t* 
     if (before_flush) *before_flush = out[0];
     bs_flush(&b);
     return b.pos;
+}
+
+/* ---- timing driver for bench.py's cpu_baseline leg when oracle/_ref is absent (kind "port"): the twin of zzref_bench in
+ * ref_harness.cpp -- native threads, static partition (item j is slice j mod nslices and belongs to thread j mod threads),
+ * every thread first-touches its own output buffer. mode 0: zzo_encode per slice; mode 1: zzo_packet over P-byte ranges. */
+typedef struct {
+    int mode, t, threads, format, level; uint32_t P;
+    const uint8_t* base; uint64_t nslices, slice_bytes, nitems; uint64_t* produced; double* secs;
+    pthread_barrier_t* start; double* w0;
+} bench_arg_t;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static void* bench_worker(void* vp)
+{
+    bench_arg_t* a = (bench_arg_t*)vp;
+    const uint64_t cap = 2 * a->slice_bytes + 4096;
+    uint8_t* out = (uint8_t*)malloc(cap);
+    memset(out, 1, cap);                                      /* allocated and touched before the clock starts */
+    pthread_barrier_wait(a->start);
+    const double t0 = now_s();
+    if (a->t == 0) *a->w0 = t0;
+    for (uint64_t j = (uint64_t)a->t; j < a->nitems; j += (uint64_t)a->threads) {
+        const uint64_t sl = j % a->nslices, at = sl * a->slice_bytes;
+        uint64_t r = 0;
+        if (a->mode == 0) r = zzo_encode(out, cap, a->base + at, a->slice_bytes, a->format, a->level);
+        else
+            for (uint64_t off = at; off < at + a->slice_bytes; off += a->P) {
+                const uint64_t ln = at + a->slice_bytes - off < a->P ? at + a->slice_bytes - off : a->P;
+                r += zzo_packet(a->level, a->base, off, ln, (sl == a->nslices - 1 && off + ln == at + a->slice_bytes) ? 1 : 0, out, cap);
+            }
+        a->produced[sl] = r;
+    }
+    a->secs[a->t] = now_s() - t0;
+    free(out);
+    return NULL;
+}
+double zzo_bench(int mode, const uint8_t* base, uint64_t nslices, uint64_t slice_bytes, uint64_t nitems, int threads,
+                 int format, int level, uint32_t P, uint64_t* produced, double* thread_secs)
+{
+    if (threads < 1) threads = 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    bench_arg_t* args = (bench_arg_t*)malloc(sizeof(bench_arg_t) * (size_t)threads);
+    double w0 = 0;
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)threads);
+    for (int t = 0; t < threads; ++t) {
+        args[t] = (bench_arg_t){ mode, t, threads, format, level, P, base, nslices, slice_bytes, nitems, produced, thread_secs, &start, &w0 };
+        if (t) pthread_create(&th[t], NULL, bench_worker, &args[t]);
+    }
+    bench_worker(&args[0]);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    const double w = now_s() - w0;
+    pthread_barrier_destroy(&start);
+    free(th); free(args);
+    return w;
 }

@@ -54,6 +54,10 @@ uint64_t zzo_packet_warm(int level, const uint8_t* base, uint64_t off, uint64_t 
  * there: the levels bring their own window). The definition is in zzoracle.c ("Extended levels"). */
 void zzo_pm_lengths(const int* freqs, int n, int maxlen, int* out);             /* optimal length-limited code lengths */
 
+/* timing driver for bench.py's cpu_baseline leg (kind "port"): see zzoracle.c */
+double zzo_bench(int mode, const uint8_t* base, uint64_t nslices, uint64_t slice_bytes, uint64_t nitems, int threads,
+                 int format, int level, uint32_t P, uint64_t* produced, double* thread_secs);
+
 /* checksums */
 uint32_t zzo_adler32(uint32_t start, const uint8_t* p, uint64_t n);             /* adler.cpp:17-43  */
 uint32_t zzo_adler_combine(uint32_t first, uint32_t second, uint64_t len2);    /* adler.cpp:5-15   */

@@ -7,6 +7,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import pytest
@@ -79,13 +80,37 @@ def _run_ranks(tmp_path, world, args):
     script.write_text(WORKER)
     res = tmp_path / "result.txt"
     port = _free_port()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT] + [str(a) for a in args] + [str(res)], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    procs, logs = [], []
+    try:
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            logs.append(open(tmp_path / f"rank{r}.log", "w+"))
+            procs.append(subprocess.Popen([sys.executable, str(script), ROOT] + [str(a) for a in args] + [str(res)], env=env,
+                                          stdout=logs[-1], stderr=subprocess.STDOUT, text=True))
+        # poll all ranks together: when one dies its peers would sit in a collective until the timeout, holding the GPU
+        deadline = time.time() + 600
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+                failed = True
+                break
+            time.sleep(0.1)
+        failed = failed or any(p.returncode != 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    outs = []
+    for f in logs:
+        f.seek(0)
+        outs.append(f.read())
+        f.close()
+    assert not failed, "\n".join(outs)
     return res.read_text()
 
 

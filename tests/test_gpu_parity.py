@@ -353,6 +353,86 @@ def test_callback_may_call_back_into_the_library(gpu, oracle, corpus):
         zz.ZzFlateEncodeToCallback(d, zz.Config(zz.Format.Zlib, 1, True), bad)
 
 
+@pytest.mark.parametrize("lvl", [0, 1, 2, 3])
+def test_multi_device_entry_point_equals_the_single_call(gpu, oracle, corpus, lvl):
+    """zz_encode_multi_device (the reference's fan-out + in-order join, zzflate.cpp:97-155, over devices of ONE process):
+    three shards on three contexts -- all of device 0 here, which still runs the concurrent encodes, the peer copies into
+    the final offsets and the host-side checksum fold -- must give the single-call stream and the oracle's."""
+    torch = gpu.torch
+    d = (corpus["lcet10.txt"] + corpus["kennedy.xls"][:300000] + corpus["alice29.txt"])[:720000]
+    P = 4096 if lvl == 3 else 32768
+    cuts = [0, 8 * 32768, 15 * 32768, len(d)]
+    ctxs = [zz.Context(0) for _ in range(3)]
+    halo = 65536
+    srcs, keep, ns, halos = [], [], [], []
+    for i in range(3):
+        lo, hi = cuts[i], cuts[i + 1]
+        h = min(halo, lo)
+        t = torch.frombuffer(bytearray(d[lo - h:hi]), dtype=torch.uint8).cuda()
+        keep.append(t)
+        srcs.append(t[h:])
+        ns.append(hi - lo)
+        halos.append(h)
+    for fmt in (0, 1, 2):
+        cap = zz.bound(len(d), fmt, lvl, P)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = zz.encode_multi(ctxs, srcs, ns, dst, cap, fmt, lvl, P, halos=halos)
+        got = dst[:w].cpu().numpy().tobytes()
+        assert got == oracle.encode_packets(d, fmt, lvl, P), (lvl, fmt)
+    # too small a destination is reported, and the contexts stay usable
+    dst = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    with pytest.raises(zz.ZzFlateError):
+        zz.encode_multi(ctxs, srcs, ns, dst, 1000, 0, lvl, P, halos=halos)
+    cap = zz.bound(len(d), 0, lvl, P)
+    dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    w = zz.encode_multi(ctxs[:1], [srcs[0]], [ns[0]], dst, cap, 0, lvl, P)
+    assert dst[:w].cpu().numpy().tobytes() == oracle.encode_packets(d[:ns[0]], 0, lvl, P)
+    with pytest.raises(zz.ZzFlateError):                     # a shard that is not a whole number of packets in front of the last
+        zz.encode_multi(ctxs[:2], [srcs[0], srcs[1]], [ns[0] - 5, ns[1]], dst, cap, 0, lvl, P)
+
+
+def test_nested_and_concurrent_callbacks_never_wait_for_the_pool(gpu, oracle, corpus):
+    """The pool holds two contexts per device. A callback that encodes (depth 2: whose callback encodes again) and two
+    threads whose callbacks both encode would wait for each other's contexts for ever if a nested call could block: it
+    gets a temporary context instead (zz_api.hip pool_acquire)."""
+    import threading
+    d, small = corpus["alice29.txt"], corpus["fields.c"]
+    want_small = oracle.encode_packets(small, 0, 2)
+    want_xargs = oracle.encode_packets(corpus["xargs.1"], 0, 1)
+    got = []
+
+    def depth2(chunk):
+        if len(got) < 1:
+            def depth3(chunk2):
+                if len(got) < 1:
+                    got.append(zz.ZzFlateEncode(corpus["xargs.1"], zz.Config(zz.Format.Zlib, 1, True)))
+            zz.ZzFlateEncodeToCallback(small, zz.Config(zz.Format.Zlib, 2, True), depth3)
+    zz.ZzFlateEncodeToCallback(d, zz.Config(zz.Format.Zlib, 1, True), depth2)
+    assert got == [want_xargs]
+
+    # two threads, both inside a callback at the same time (a barrier makes sure of it), both encoding from there
+    inside = threading.Barrier(2, timeout=60)
+    results, errors = [None, None], []
+
+    def worker(t):
+        done = []
+
+        def cb(chunk):
+            if not done:
+                done.append(1)
+                inside.wait()                      # both outer calls hold a context of device 0 now: the pool is full
+                results[t] = zz.ZzFlateEncode(small, zz.Config(zz.Format.Zlib, 2, True))
+        try:
+            zz.ZzFlateEncodeToCallback(d, zz.Config(zz.Format.Zlib, 1, True), cb)
+        except Exception as e:                     # noqa: BLE001
+            errors.append(e)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [t.start() for t in ths]
+    [t.join(120) for t in ths]
+    assert not any(t.is_alive() for t in ths), "nested calls from two threads blocked each other"
+    assert not errors and results == [want_small, want_small]
+
+
 @pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 13, 15, 16, 17])
 def test_tiny_packets_at_the_end_of_an_allocation(gpu, oracle, P):
     """Packets shorter than the 16-byte loads: bounds-checked loads are chosen by bytes, not by packet index, so

@@ -78,6 +78,9 @@ def _load():
         "zz_encode_stream_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, vp]),
         "zz_encode_stream_chunks_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, pu64, u32, ctypes.POINTER(u32), vp]),
         "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
+        "zz_encode_shard_device_async": (i32, [vp, vp, u64, u64, i32, vp, u64, i32, i32, u32, vp]),
+        "zz_encode_shard_finish": (i32, [vp, pu64, ctypes.POINTER(u32), i32]),
+        "zz_encode_multi_device": (i32, [ctypes.POINTER(vp), i32, ctypes.POINTER(vp), pu64, pu64, vp, u64, pu64, i32, i32, u32]),
         "zz_verify_last_device": (i32, [vp, pu64, pu64, vp]),
         "zz_packet_extent_device": (i32, [vp, u64, pu64, pu64, vp]),
         "zz_header": (i32, [i32, vp]),
@@ -292,6 +295,19 @@ class Context:
                                           ctypes.byref(out), ctypes.byref(cks), int(checksum), int(level), packet_size, st))
         return out.value, cks.value
 
+    def encode_shard_async(self, src, n, dst, cap, halo=0, is_last=True, checksum=Format.Zlib, level=1,
+                           packet_size=DEFAULT_PACKET, stream=None):
+        """Enqueue one shard and return; `finish_shard` waits for it. src, dst and the stream must stay alive."""
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_shard_device_async(self._h, self._ptr(src), n, halo, 1 if is_last else 0, self._ptr(dst), cap,
+                                                int(checksum), int(level), packet_size, st))
+
+    def finish_shard(self, checksum=Format.Zlib):
+        out = ctypes.c_uint64(0)
+        cks = ctypes.c_uint32(0)
+        _check(lib.zz_encode_shard_finish(self._h, ctypes.byref(out), ctypes.byref(cks), int(checksum)))
+        return out.value, cks.value
+
     def verify_last(self, stream=None):
         """Inflates every packet of the last encode / encode_shard call's output on the device and compares with its
         input (both tensors must still be alive): returns (bad packets, lowest bad packet or None)."""
@@ -310,3 +326,17 @@ class Context:
     def generate(self, kind, seed, first_byte, buf, n, stream=None):
         st = self._stream() if stream is None else stream
         _check(lib.zz_generate_device(self._h, kind, seed, first_byte, self._ptr(buf), n, st))
+
+
+def encode_multi(ctxs, srcs, ns, dst, cap, format=Format.Zlib, level=1, packet_size=DEFAULT_PACKET, halos=None):
+    """zz_encode_multi_device: shard i = srcs[i][:ns[i]] on the device of ctxs[i]; the whole stream (header, shards in
+    order, trailer) lands in `dst` on the device of ctxs[0]. One process, no torch.distributed. Returns the byte count."""
+    k = len(ctxs)
+    vp = ctypes.c_void_p
+    cs = (vp * k)(*[c._h for c in ctxs])
+    ps = (vp * k)(*[Context._ptr(t) for t in srcs])
+    nn = (ctypes.c_uint64 * k)(*ns)
+    hh = (ctypes.c_uint64 * k)(*(halos or [0] * k))
+    out = ctypes.c_uint64(0)
+    _check(lib.zz_encode_multi_device(cs, k, ps, nn, hh, Context._ptr(dst), cap, ctypes.byref(out), int(format), int(level), packet_size))
+    return out.value

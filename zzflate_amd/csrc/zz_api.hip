@@ -77,6 +77,15 @@ struct zz_ctx {
     bool have_time = false;
 };
 
+// Small host values (an empty input's block, a result record whose size is known up front) reach the device as kernel
+// ARGUMENTS -- copied at launch -- not as asynchronous copies from stack locals, which would still be read after an
+// enqueue-only call (zz_encode_device_async) has returned.
+__global__ void k_put_small(uint8_t* dst, uint64_t bytes, uint32_t nbytes, zz_result* res, uint64_t stream_bytes)
+{
+    for (uint32_t i = 0; i < nbytes; ++i) dst[i] = (uint8_t)(bytes >> (8 * i));
+    if (res) res->stream_bytes = stream_bytes;
+}
+
 static int header_len(int format) { return format == ZZ_ZLIB ? 2 : format == ZZ_GZIP ? 10 : 0; }
 static int trailer_len(int format) { return format == ZZ_ZLIB ? 4 : format == ZZ_GZIP ? 8 : 0; }
 
@@ -139,6 +148,7 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->pend.active) { (void)hipStreamSynchronize(c->pend.st); c->pend.active = false; }   // an enqueued call still uses the buffers
     (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
     (void)hipFree(c->l2_scratch);
     (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
@@ -277,9 +287,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         else if (level == 0) { blk[0] = 1; blk[1] = 0; blk[2] = 0; blk[3] = 0xFF; blk[4] = 0xFF; bl = 5; }
         else { blk[0] = 0x03; blk[1] = 0x00; bl = 2; }
         if ((uint64_t)hl + bl + tl > cap) { set_err("destination too small"); return ZZ_E_NOSPACE; }
-        if (bl) HIPCHK(hipMemcpyAsync(d_dst + hl, blk, bl, hipMemcpyHostToDevice, st));
-        zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = bl;
-        HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
+        uint64_t packed = 0;
+        for (uint32_t i = 0; i < bl; ++i) packed |= (uint64_t)blk[i] << (8 * i);
+        hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, d_dst + hl, packed, bl, c->d_res, (uint64_t)bl);
     } else {
         int rc = ensure_workspace(c, level, npk, stride);
         if (rc) return rc;
@@ -301,8 +311,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             zz_l0_params q; q.pk = pp; q.dst = d_dst + hl; q.stream_mode = 0;
             uint32_t g = npk < 16384 ? npk : 16384;
             hipLaunchKernelGGL(k_encode_l0, dim3(g), dim3(256), 0, st, q);
-            zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
-            HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, (uint8_t*)nullptr, 0ull, 0u, c->d_res, total);
         } else if (level == 1) {
             // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
@@ -412,6 +421,7 @@ static int cks_kind_for(int format) { return format == ZZ_ZLIB ? ZZ_CKS_ADLER : 
 static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d_dst, uint64_t cap, int format, int level,
                          bool chunked, std::vector<uint64_t>* chunk_sizes, hipStream_t st, zz_result* host_res)
 {
+    if (c->pend.active) { set_err("a call enqueued with zz_encode_device_async has not been finished on this context"); return ZZ_E_ARG; }
     if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
     if (!d_dst || (!d_src && n)) { set_err("null buffer"); return ZZ_E_ARG; }
     if (chunk_sizes) chunk_sizes->clear();
@@ -449,8 +459,7 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
         }
         zz_l0_params q; q.pk = pp; q.dst = d_dst + hl; q.stream_mode = 1;
         hipLaunchKernelGGL(k_encode_l0, dim3(npk < 16384 ? npk : 16384), dim3(256), 0, st, q);
-        zz_result r0; memset(&r0, 0, sizeof r0); r0.stream_bytes = total;
-        HIPCHK(hipMemcpyAsync(c->d_res, &r0, sizeof r0, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, (uint8_t*)nullptr, 0ull, 0u, c->d_res, total);
         if (cks_kind != ZZ_CKS_NONE)
             hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk, B, n, cks_kind, c->d_cks_total);
         if (chunked && chunk_sizes)                                     // WriteUncompressedBlock asks for 6 + length (encoder.cpp:488)
@@ -634,6 +643,112 @@ extern "C" int zz_encode_shard_device(zz_ctx* c, const void* d_src, uint64_t n, 
     return ZZ_OK;
 }
 
+// The shard call in two halves (as zz_encode_device_async / zz_encode_finish): a rank can enqueue the next step's shard
+// before it has exchanged the previous one's size and checksum with its peers, so the GPU never waits for the host.
+extern "C" int zz_encode_shard_device_async(zz_ctx* c, const void* d_src, uint64_t n, uint64_t halo, int is_last, void* d_dst,
+                                            uint64_t cap, int checksum, int level, uint32_t P, void* hip_stream)
+{
+    if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
+    if (P == 0) P = ZZ_DEFAULT_PACKET;
+    return encode_common(c, (const uint8_t*)d_src, n, halo, is_last != 0, (uint8_t*)d_dst, cap, ZZ_DEFLATE, cks_kind_for(checksum),
+                         false, level, P, (hipStream_t)hip_stream, nullptr);
+}
+extern "C" int zz_encode_shard_finish(zz_ctx* c, uint64_t* out_len, uint32_t* cks, int checksum)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!c || !out_len) { set_err("null ctx/out_len"); return ZZ_E_ARG; }
+    zz_result r;
+    int rc = encode_finish(c, &r);
+    if (rc) return rc;
+    *out_len = r.stream_bytes;
+    if (cks) *cks = checksum == ZZ_ZLIB ? ((r.cks_b << 16) | r.cks_a) : r.cks_a;
+    return ZZ_OK;
+}
+
+static int ensure_stage(zz_ctx* c, uint64_t in_bytes, uint64_t out_bytes);
+extern "C" int zz_header(int format, uint8_t out[10]);
+extern "C" int zz_trailer(int format, uint32_t v, uint64_t n, uint8_t out[8]);
+// The reference's fan-out and join (WriteDeflateStream, zzflate.cpp:97-155: ranges -> std::async encoders -> in-order
+// memmove) for data that is ALREADY RESIDENT on several GPUs of one process -- the north star's dataflow without
+// torch.distributed. Shard i (contiguous ranges of one stream, in order, every shard but the last a whole number of
+// packets) lives on the device of ctxs[i]; all shards are encoded concurrently, each on its own device and stream; as
+// shard i finishes, its compressed bytes are pulled over xGMI (hipMemcpyPeerAsync) straight to their final offset in
+// d_dst, which lives on the device of ctxs[0] (shard 0 is encoded in place there); the checksum partials are folded on
+// the host (adler.cpp:5-15 / GF(2) shifts) and header and trailer are written around the stream. No bulk collective.
+extern "C" int zz_encode_multi_device(zz_ctx* const* ctxs, int nshards, const void* const* d_src, const uint64_t* n,
+                                      const uint64_t* halo, void* d_dst, uint64_t cap, uint64_t* out_len, int format, int level,
+                                      uint32_t P)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!ctxs || nshards < 1 || !d_src || !n || !d_dst || !out_len) { set_err("null argument"); return ZZ_E_ARG; }
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    if (P == 0) P = ZZ_DEFAULT_PACKET;
+    if (P > ZZ_MAX_PACKET_SIZE) { set_err("packet size must be 1..32768"); return ZZ_E_ARG; }
+    for (int i = 0; i < nshards; ++i) {
+        if (!ctxs[i]) { set_err("null context"); return ZZ_E_ARG; }
+        for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) { set_err("every shard needs a context of its own"); return ZZ_E_ARG; }
+        if (i + 1 < nshards && n[i] % P) { set_err("every shard but the last must be a whole number of packets"); return ZZ_E_ARG; }
+        if (i + 1 < nshards && n[i] == 0) { set_err("empty shard in front of the last one"); return ZZ_E_ARG; }
+    }
+    const int hl = header_len(format), tl = trailer_len(format);
+    if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
+    uint8_t* dst = (uint8_t*)d_dst;
+    zz_ctx* c0 = ctxs[0];
+    // enqueue every shard on its own device and stream; nothing waits yet
+    std::vector<uint64_t> bound(nshards);
+    for (int i = 0; i < nshards; ++i) {
+        zz_ctx* c = ctxs[i];
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->s_enc) HIPCHK(hipStreamCreateWithFlags(&c->s_enc, hipStreamNonBlocking));
+        bound[i] = zz_bound(n[i], ZZ_DEFLATE, level > 3 ? 3 : level, P);
+        uint8_t* out = nullptr;
+        uint64_t ocap = 0;
+        if (i == 0) { out = dst + hl; ocap = cap - hl; }               // final place: offset known
+        else { int rc = ensure_stage(c, 0, bound[i]); if (rc) return rc; out = c->stage_out; ocap = c->stage_out_cap; }
+        int rc = zz_encode_shard_device_async(c, d_src[i], n[i], halo ? halo[i] : 0, i + 1 == nshards, out, ocap, format, level, P,
+                                              (void*)c->s_enc);
+        if (rc) {           // finish what was enqueued so far: the contexts stay usable
+            for (int j = 0; j < i; ++j) { uint64_t w; (void)zz_encode_shard_finish(ctxs[j], &w, nullptr, format); }
+            return rc;
+        }
+    }
+    // in-order join: shard i's offset is the sum of the sizes in front of it
+    uint64_t off = (uint64_t)hl;
+    uint32_t acc = format == ZZ_ZLIB ? 1u : 0u;
+    uint64_t total_in = 0;
+    int err = ZZ_OK;
+    std::string errmsg;
+    for (int i = 0; i < nshards; ++i) {
+        zz_ctx* c = ctxs[i];
+        uint64_t w = 0; uint32_t part = 0;
+        int rc = zz_encode_shard_finish(c, &w, &part, format);
+        if (rc && !err) { err = rc; errmsg = g_err; }
+        if (err) continue;                                            // keep finishing: no context is left with a pending call
+        if (off + w + (uint64_t)tl > cap) { err = ZZ_E_NOSPACE; errmsg = "destination too small for the compressed stream"; continue; }
+        if (i > 0 && w) {
+            if (hipSetDevice(c->device) != hipSuccess ||
+                hipMemcpyPeerAsync(dst + off, c0->device, c->stage_out, c->device, w, c->s_enc) != hipSuccess) {
+                err = ZZ_E_HIP; errmsg = "hipMemcpyPeerAsync failed"; continue;
+            }
+        }
+        acc = format == ZZ_ZLIB ? adler_combine(acc, part, n[i]) : format == ZZ_GZIP ? crc32_combine(acc, part, n[i]) : 0u;
+        off += w;
+        total_in += n[i];
+    }
+    for (int i = 1; i < nshards; ++i) {                               // the pulls have landed
+        (void)hipSetDevice(ctxs[i]->device);
+        if (hipStreamSynchronize(ctxs[i]->s_enc) != hipSuccess && !err) { err = ZZ_E_HIP; errmsg = "hipStreamSynchronize failed after the peer copies"; }
+    }
+    if (err) { set_err(errmsg); return err; }
+    HIPCHK(hipSetDevice(c0->device));
+    uint8_t hdr[10], trl[8];
+    const int hn = zz_header(format, hdr), tn = zz_trailer(format, acc, total_in, trl);
+    if (hn) HIPCHK(hipMemcpy(dst, hdr, (size_t)hn, hipMemcpyHostToDevice));
+    if (tn) HIPCHK(hipMemcpy(dst + off, trl, (size_t)tn, hipMemcpyHostToDevice));
+    *out_len = off + (uint64_t)tn;
+    return ZZ_OK;
+}
+
 // ---- container pieces --------------------------------------------------------------------------------
 extern "C" int zz_header(int format, uint8_t out[10])
 {
@@ -694,6 +809,10 @@ static std::mutex g_mu;
 static std::condition_variable g_cv;
 static uint32_t g_packet = 0;
 struct pool_entry { zz_ctx* c; bool busy; };
+// contexts the calling THREAD holds through host calls further up its stack (a callback that calls back into the
+// library): such a call must never wait for the pool -- the contexts it would wait for may be its own, or belong to
+// another thread whose callback is waiting the same way -- so it gets a temporary context beyond the cap instead.
+static thread_local int tl_leases = 0;
 static std::vector<pool_entry> g_pool;
 static std::vector<int> g_devices;
 #define ZZ_POOL_PER_DEVICE 2
@@ -755,10 +874,13 @@ static int host_devices(std::vector<int>& out)
 extern "C" void zz_debug_reset_devices(void) { std::lock_guard<std::mutex> lk(g_mu); g_devices.clear(); }
 
 // `held`: contexts of this device the calling host call already holds (ZZFLATE_DEVICES may name a device several
-// times). A call only ever waits for its first context of a device -- it never holds one while waiting for another --
-// so concurrent calls cannot block each other for good.
-static int pool_acquire(int device, int held, zz_ctx** out)
+// times). A call only ever waits for its first context of a device, devices are taken in one global order, and a
+// `nested` call (its thread holds contexts through calls further up its stack) never waits at all: concurrent and
+// nested calls cannot block each other for good.
+// *temp = the context was created beyond the cap for a nested call and is destroyed on release.
+static int pool_acquire(int device, int held, bool nested, zz_ctx** out, bool* temp)
 {
+    *temp = false;
     std::unique_lock<std::mutex> lk(g_mu);
     for (;;) {
         int have = 0;
@@ -773,12 +895,13 @@ static int pool_acquire(int device, int held, zz_ctx** out)
                 if (!e.busy) { e.busy = true; e.c->warm = warm; e.c->extended = ext; *out = e.c; return ZZ_OK; }
                 have++;
             }
-        if (have < ZZ_POOL_PER_DEVICE + held) {
+        if (have < ZZ_POOL_PER_DEVICE + held || nested) {
             zz_ctx* c = nullptr;
             int rc = zz_ctx_create(device, &c);
             if (rc) return rc;
             c->warm = warm; c->extended = ext;
-            g_pool.push_back({ c, true });
+            if (have < ZZ_POOL_PER_DEVICE + held) g_pool.push_back({ c, true });
+            else *temp = true;
             *out = c;
             return ZZ_OK;
         }
@@ -792,14 +915,21 @@ static void pool_release(zz_ctx* c)
 }
 struct ctx_lease {                       // contexts borrowed for one host call
     std::vector<zz_ctx*> v;
-    ~ctx_lease() { for (zz_ctx* c : v) pool_release(c); }
+    std::vector<bool> temp;
+    const int outer = tl_leases;         // contexts held by host calls further up this thread's stack
+    ~ctx_lease()
+    {
+        for (size_t i = 0; i < v.size(); ++i) { if (temp[i]) zz_ctx_destroy(v[i]); else pool_release(v[i]); }
+        tl_leases -= (int)v.size();
+    }
     int take(int device)
     {
         int held = 0;
         for (zz_ctx* h : v) held += h->device == device;
         zz_ctx* c = nullptr;
-        int rc = pool_acquire(device, held, &c);
-        if (!rc) v.push_back(c);
+        bool t = false;
+        int rc = pool_acquire(device, held, outer > 0, &c, &t);
+        if (!rc) { v.push_back(c); temp.push_back(t); tl_leases++; }
         return rc;
     }
 };
