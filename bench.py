@@ -96,10 +96,10 @@ def cpu_baseline(sample: bytes, level: int, fmt: int, P: int = 32768):
 
     out = {}
     for mode, name in ((0, "whole"), (1, "packets")):
-        # one thread: ~4 slices (0.3-0.6 s at level 1); all cores: every slice at least once, every thread ~6 slices
-        # (~1 s of work each at level 1, more at level 2): the whole leg stays within ~10-30 s
+        # one thread: ~4 slices (0.2-0.5 s at level 1); all cores: every slice at least once, every thread 24 slices
+        # (1-3 s of work each at level 1, more at level 2): ~10-30 s of CPU work per form
         one, one_wall, _, _ = run(mode, 1, min(4, nslices))
-        per_thread = 6
+        per_thread = 24
         nitems = max(nslices, per_thread * cores)
         allv, wall, produced, secs = run(mode, cores, nitems)
         eff = (allv / cores) / one if one > 0 else None

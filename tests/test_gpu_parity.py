@@ -532,9 +532,10 @@ def test_warm_window_level1(gpu, oracle, corpus, warm):
 
 
 def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
-    """levels 4, 5, 6 (off unless switched on) = the level-2 encoder with a warm window of 4, 16, 32 KiB.
-    Bit-exact with the oracle's restatement (level 2 + that window), valid DEFLATE, never larger than level 3 on the
-    text files, and the same window is available at levels 2, 3 through zz_ctx_set_warm_window."""
+    """levels 4, 5, 6 (off unless switched on) = hash chains of depth 2 / 4 / 8 over a window of 8 / 32 /
+    32 KiB, one-step lazy matching, package-merge code lengths (zz_level6.h). Bit-exact with the oracle's definition
+    (oracle/zzoracle.c "Extended levels"), valid DEFLATE (zlib and the device decoder), smaller than level 3 on the text
+    files by more than 5 % at level 6; and a warm window is available at levels 2, 3 through zz_ctx_set_warm_window."""
     import torch
     ctx = zz.Context(0)
 
@@ -555,16 +556,38 @@ def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
     for fname in CORPUS_FILES:
         d = corpus[fname]
         l3 = gpu.encode(d, 0, 3)
-        for lvl, warm in ((4, 4096), (5, 16384), (6, 32768)):
+        for lvl in (4, 5, 6):
             got = enc(d, 0, lvl)
-            assert got == oracle.encode_packets(d, 0, 2, warm=warm), (fname, lvl)
+            assert got == oracle.encode_packets(d, 0, lvl), (fname, lvl)
             assert zlib.decompress(got) == d
             if fname.endswith(".txt"):
                 assert len(got) < len(l3), (fname, lvl)
+                if lvl == 6:
+                    assert len(got) < 0.95 * len(l3), fname
+        for P in (4096, 1000):
+            assert enc(d[:200000], 1, 6, P) == oracle.encode_packets(d[:200000], 1, 6, P), (fname, P)
     for kind in SYNTH_KINDS + ["longperiod"]:
-        for n, P in ((70000, 32768), (100000, 4096), (33000, 1000)):
+        for n, P in ((70000, 32768), (100000, 4096), (33000, 1000), (5000, 777)):
             d = synth(kind, n, 31)
-            assert enc(d, 2, 6, P) == oracle.encode_packets(d, 2, 2, P, warm=32768), (kind, n, P)
+            for lvl in (4, 5, 6):
+                assert enc(d, 2, lvl, P) == oracle.encode_packets(d, 2, lvl, P), (kind, n, P, lvl)
+    for n in EDGE_SIZES:
+        d = synth("words", n, 5)
+        assert enc(d, 2, 6) == oracle.encode_packets(d, 2, 6), n
+        d = synth("runs", n, 6)
+        assert enc(d, 2, 5, 4096) == oracle.encode_packets(d, 2, 5, 4096), n
+    # shards: the window is the shard's halo
+    d = corpus["lcet10.txt"] + corpus["ptt5"][:200000]
+    buf = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cut = 6 * 32768
+    parts = []
+    for off, n, last in ((0, cut, False), (cut, len(d) - cut, True)):
+        cap = zz.bound(n, 2, 2)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w, _ = ctx.encode_shard(buf.data_ptr() + off, n, dst, cap, halo=off, is_last=last, checksum=zz.Format.Deflate, level=6)
+        assert ctx.verify_last() == (0, None)
+        parts.append(dst[:w].cpu().numpy().tobytes())
+    assert b"".join(parts) == oracle.encode_packets(d, 2, 6)
     ctx.set_extended_levels(False)
     ctx.set_warm_window(8192)
     d = corpus["lcet10.txt"]
@@ -584,13 +607,13 @@ def test_warm_window_candidates_at_the_very_start_of_the_stream(gpu, oracle):
     try:
         src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
         for P in (1024, 777):
-            for lvl, warm in ((5, 16384), (6, 32768), (4, 4096), (2, 32768), (3, 1000)):
+            for lvl, warm in ((5, 0), (6, 0), (4, 0), (2, 32768), (3, 1000)):
                 ctx.set_warm_window(warm if lvl < 4 else 0)
                 cap = zz.bound(len(d), 1, 3, P)
                 dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
                 w = ctx.encode(src, len(d), dst, cap, zz.Format.Gzip, lvl, P)
                 got = dst[:w].cpu().numpy().tobytes()
-                assert got == oracle.encode_packets(d, 1, lvl if lvl < 4 else 2, P, warm=warm), (P, lvl)
+                assert got == oracle.encode_packets(d, 1, lvl, P, warm=warm), (P, lvl)
                 assert zlib.decompressobj(31).decompress(got) == d
     finally:
         ctx.set_warm_window(0)

@@ -95,8 +95,7 @@ for it in range(cases):
         dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
         w = ctx.encode(src, len(d), dst, cap, fmt, elvl, P)
         got = dst[:w].cpu().numpy().tobytes()
-        ow = {4: 4096, 5: 16384, 6: 32768}.get(elvl, warm)
-        want = o.encode_packets(d, fmt, 2 if elvl > 3 else lvl, P, warm=ow)
+        want = o.encode_packets(d, fmt, elvl if elvl > 3 else lvl, P, warm=0 if elvl > 3 else warm)
         vb, _ = ctx.verify_last() if len(d) else (0, None)
         if got != want or zlib.decompressobj(WB[fmt]).decompress(got) != d or vb:
             bad += 1

@@ -177,7 +177,8 @@ extern "C" int zz_debug_occupancy(int level)
 {
     int nb = -1;
     if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
-    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u>, ZZ_L2_THREADS, 0);
+    else if (level >= 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<32768u, 8>, ZZ_L2_THREADS, 0);
+    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, 0>, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
 }
@@ -216,7 +217,7 @@ extern "C" double zz_ctx_last_kernel_ms(zz_ctx* c)
     return ms;
 }
 
-static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
+static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride, int xdepth = 0)
 {
     if (npk > c->npk_cap) {
         (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
@@ -235,7 +236,7 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride)
         }
     }
     if (level >= 2) {
-        uint64_t need = (uint64_t)l2_grid((uint32_t)npk) * ZZ_L2_SCRATCH_BYTES;
+        uint64_t need = l2_scratch_bytes((uint32_t)npk, xdepth);
         if (need > c->l2_scratch_cap) {
             (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
             HIPCHK(hipMalloc(&c->l2_scratch, need));
@@ -254,11 +255,13 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
 {
     if (c->pend.active) { set_err("a call enqueued with zz_encode_device_async has not been finished on this context"); return ZZ_E_ARG; }
     // Levels 4..6 are beyond the reference (which rejects them, zzflate.cpp:201,230) and only exist when switched on:
-    // the level-2 encoder (dynamic Huffman) with a warm window of 4 / 16 / 32 KiB in front of every packet.
+    // hash chains of depth 2 / 4 / 8 over a window of 8 / 32 / 32 KiB in front of every packet, lazy matching, package-merge
+    // code lengths (zz_level6.h), in the level-2 kernel's frame (dynamic blocks, stored fallback).
     uint32_t warm = level >= 1 ? c->warm : 0;
+    int xdepth = 0;
     if (level >= 4 && level <= 6 && c->extended) {
-        const uint32_t w = level == 4 ? 4096u : level == 5 ? 16384u : 32768u;
-        if (w > warm) warm = w;
+        xdepth = level == 4 ? 2 : level == 5 ? 4 : 8;
+        warm = level == 4 ? 8192u : 32768u;            // the levels bring their own window (zz_ctx_set_warm_window is for levels 1..3)
         level = 2;
     }
     if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
@@ -291,7 +294,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         for (uint32_t i = 0; i < bl; ++i) packed |= (uint64_t)blk[i] << (8 * i);
         hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, d_dst + hl, packed, bl, c->d_res, (uint64_t)bl);
     } else {
-        int rc = ensure_workspace(c, level, npk, stride);
+        int rc = ensure_workspace(c, level, npk, stride, xdepth);
         if (rc) return rc;
         zz_packet_params pp;
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
@@ -318,7 +321,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
             else hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
         } else {
-            launch_level2(pp, c->l2_scratch, c->d_work, st);
+            launch_level2(pp, c->l2_scratch, c->d_work, st, xdepth);
         }
         if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
         if (level != 0) {

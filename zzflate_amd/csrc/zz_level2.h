@@ -828,10 +828,9 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
 // records through nrec_out.
 __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
                                                    uint32_t* tokens, uint16_t* recs, const uint8_t* src, uint32_t n,
-                                                   uint32_t& nrec_out, uint32_t& adA, uint64_t& adC)
+                                                   uint32_t& nrec_out, uint32_t& adA, uint64_t& adC, const uint32_t trips)
 {
     const int lane = lane_id();
-    const uint32_t trips = l2_probe_blocks(n);
     uint32_t nrec = 0, Fnext = 0, ntok = 0;
     // Adler-32 on the way: every byte below n passes through this wave once (as the byte of a finished block), so the
     // per-lane sums of d and position * d (wave_adler's A and C) cost two instructions here instead of a pass of their own
@@ -982,6 +981,10 @@ __device__ __forceinline__ uint32_t l2_count_bits(const uint16_t* recs, const ui
     return wave_sum(acc);
 }
 
+}  // namespace zz
+#include "zz_level6.h"
+namespace zz {
+
 struct zz_l2_params {
     zz_packet_params pk;
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
@@ -999,8 +1002,11 @@ struct zz_l2_params {
 // wavefront 1 keeps the books (matches to scratch, bitmap window, symbol counts, finished blocks to records, the
 // Adler-32 sums), one s_barrier per 64-position block. Afterwards wavefront 0 builds the codes and both emit.
 // BIAS = 32768: the same with a warm window (P.warm bytes in front of every packet are hashed into its table first).
-template <uint32_t BIAS>
-__global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q)
+// XD > 0: the extended levels 4..6 (zz_level6.h) -- chains of depth XD instead of the one-slot table, lazy parse, package-merge
+// code lengths; everything behind the token pass and the code lengths is shared. Eight candidates in flight want more
+// registers: four wavefronts per SIMD instead of five, i.e. eight workgroups per CU.
+template <uint32_t BIAS, int XD = 0>
+__global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
     // ---- LDS carve-up: 17,840 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
@@ -1032,13 +1038,23 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
     uint8_t* metaLens = (uint8_t*)(lds + 7232);    // 32
     uint32_t* metaCodes = (uint32_t*)(lds + 7264); // 80
     uint16_t* rle = (uint16_t*)(lds + 7344);       // up to 316+30 records -> 704 bytes
+    // XD: package-merge scratch in the same (dead) space, in front of `lens`
+    pm_scratch PM;
+    PM.sym = (uint16_t*)(lds);                     // 576
+    PM.w = (uint32_t*)(lds + 576);                 // 1152
+    PM.pk = (uint32_t*)(lds + 1728);               // 1152
+    PM.cur = (uint32_t*)(lds + 2880);              // 2304
+    PM.bm = (uint64_t*)(lds + 5184);               // 1152
+    PM.misc = (uint32_t*)(lds + 6336);             // 128 (.. 6464 < 6912)
 
     const int lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
     ZZ_PROF_DECL
-    uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES;
+    uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * (ZZ_L2_SCRATCH_BYTES + (XD ? ZZ_L6_SCRATCH_BYTES : 0u));
     uint32_t* tokens = (uint32_t*)my_scratch;                                   // matches in stream order
     uint16_t* recs = (uint16_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 4);            // records in stream order
+    uint16_t* const xsorted = (uint16_t*)(my_scratch + ZZ_L2_SCRATCH_BYTES);    // XD: positions sorted by (hash, position)
+    uint16_t* const xidx = (uint16_t*)(my_scratch + ZZ_L2_SCRATCH_BYTES + ZZ_L6_SORT_BYTES);
 
     // Persistent workgroups: the first packet is the workgroup's index, every further one comes from a counter, so
     // that packets of unequal cost (stored fallback vs. dynamic block) do not leave workgroups idle at the end.
@@ -1076,7 +1092,22 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
 
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
-            if (W0) {
+            if (XD) {
+                // the extended levels: counting sort of all positions by hash (histogram + scan here, the array zeroed by
+                // the helper meanwhile), then the chains are one load per position (zz_level6.h)
+                const int32_t Wn = (int32_t)(before < P.warm ? before : P.warm);
+                const uint32_t xtarget = l6_target(n);
+                if (W0) l6_histogram_and_scan(T, src, Wn, xtarget);
+                else l6_zero_sorted(xsorted, ZZ_L6_PAD + (uint32_t)Wn + xtarget);
+                __syncthreads();
+                if (W0) {
+                    l6_place_all(T, (uint32_t)(ZZ_L2_LDS_BYTES / 2), src, Wn, xtarget, xsorted, xidx);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the places are in memory ...
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and no stale line of the previous packet's is in the L1
+                    if (off + len + 16 > P.n) l6_match_pass<XD ? XD : 1, true>(hb, src, end, n, xsorted, xidx);
+                    else l6_match_pass<XD ? XD : 1, false>(hb, src, end, n, xsorted, xidx);
+                }
+            } else if (W0) {
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
                     // own three bytes (CalcHash(source + j), :388), ascending, per hash the highest stays
@@ -1109,10 +1140,11 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
                 if (off + len + 16 > P.n) l2_token_pass<true, BIAS>(T, hb, src, end, n, before, P.prof);
                 else l2_token_pass<false, BIAS>(T, hb, src, end, n, before, P.prof);
-            } else {
+            }
+            if (!W0) {
                 uint32_t nb = 0, adA = 0;
                 uint64_t adC = 0;
-                const uint32_t nt = l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC);
+                const uint32_t nt = l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, XD ? l6_trips(n) : l2_probe_blocks(n));
                 if (lane == 0) { covw[0] = ((uint64_t)nt << 32) | nb; }       // the window is dead now
                 if (P.cks_kind == ZZ_CKS_ADLER) {
                     if (lane == 0 && len > n) { const uint32_t d = src[n]; adA += d; adC += (uint64_t)n * d; }   // the byte of the alignment block
@@ -1188,13 +1220,13 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
             // ================= code construction =================================================================
             if (lane == 0) symF[256] += 1;                                       // :470
             ZZ_WAVE_SYNC();
-            calc_lengths_w(S, symF, 286, 15, lens);                              // ComputeCodes, :171-176
+            if (XD) pm_lengths_w(PM, symF, 286, 15, lens); else calc_lengths_w(S, symF, 286, 15, lens);   // ComputeCodes, :171-176
             uint32_t bitsum = 0;
             for (int i = lane; i < 286; i += ZZ_WAVE) {                          // CountBits, :178-187
                 const uint32_t eb = i < 265 || i == 285 ? 0 : (uint32_t)(i - 261) >> 2;
                 bitsum += symF[i] * (lens[i] + eb);
             }
-            calc_lengths_w(S, distF, 30, 15, lens + 288);
+            if (XD) pm_lengths_w(PM, distF, 30, 15, lens + 288); else calc_lengths_w(S, distF, 30, 15, lens + 288);
             if (lane < 30) {
                 const uint32_t eb = lane < 4 ? 0 : (uint32_t)(lane - 2) >> 1;
                 bitsum += distF[lane] * (lens[288 + lane] + eb);
@@ -1205,7 +1237,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
                 misc[2] = (uint32_t)rle_lengths(lens + 288, 30, rle, nr, metaF);
             }
             ZZ_WAVE_SYNC();
-            calc_lengths_w(S, metaF, 19, 7, metaLens);                           // :263-265
+            if (XD) pm_lengths_w(PM, metaF, 19, 7, metaLens); else calc_lengths_w(S, metaF, 19, 7, metaLens);   // :263-265
             const uint32_t nrec = misc[2];
             for (uint32_t i = lane; i < nrec; i += ZZ_WAVE) {                    // WriteLengths<LengthCounter>, :20-46
                 const uint32_t v = rle[i] & 0xFF;
@@ -1306,17 +1338,26 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
     ZZ_PROF_FLUSH(P);
 }
 
-static inline uint32_t l2_grid(uint32_t npk)
+// xdepth: 0 = levels 2,3; 2 / 4 / 8 = the extended levels 4 / 5 / 6 (chain depth)
+static inline uint32_t l2_grid(uint32_t npk, int xdepth = 0)
 {
-    const uint32_t resident = 256 * 9;      // CUs x workgroups the LDS budget admits
+    const uint32_t resident = 256 * (xdepth ? 8 : 9);      // CUs x workgroups the LDS (xdepth: the register) budget admits
     return npk < resident ? npk : resident;
 }
-static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st)
+static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth)
+{
+    return (uint64_t)l2_grid(npk, xdepth) * (ZZ_L2_SCRATCH_BYTES + (xdepth ? ZZ_L6_SCRATCH_BYTES : 0u));
+}
+static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st, int xdepth = 0)
 {
     zz_l2_params q; q.pk = pp; q.scratch = scratch; q.work = work;
     (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
-    if (pp.warm) hipLaunchKernelGGL(k_encode_l2_t<32768u>, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
-    else hipLaunchKernelGGL(k_encode_l2_t<0u>, dim3(l2_grid(pp.npk)), dim3(ZZ_L2_THREADS), 0, st, q);
+    const dim3 g(l2_grid(pp.npk, xdepth)), b(ZZ_L2_THREADS);
+    if (xdepth == 2) hipLaunchKernelGGL((k_encode_l2_t<32768u, 2>), g, b, 0, st, q);
+    else if (xdepth == 4) hipLaunchKernelGGL((k_encode_l2_t<32768u, 4>), g, b, 0, st, q);
+    else if (xdepth == 8) hipLaunchKernelGGL((k_encode_l2_t<32768u, 8>), g, b, 0, st, q);
+    else if (pp.warm) hipLaunchKernelGGL((k_encode_l2_t<32768u, 0>), g, b, 0, st, q);
+    else hipLaunchKernelGGL((k_encode_l2_t<0u, 0>), g, b, 0, st, q);
 }
 
 }  // namespace zz
