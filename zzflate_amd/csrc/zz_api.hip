@@ -97,9 +97,6 @@ static uint32_t slot_stride_for(int level, uint32_t P)
     else if (level == 1) b = ((uint64_t)9 * P + 10 + 7) / 8 + 6;   // 3 + 9 bits/byte + EOB, + 1-byte stored block
     else b = (uint64_t)P + 11;                                      // stored fallback is the worst case
     b += 8;                                                         // the ring stores whole words
-#ifdef ZZ_L1_TENWG
-    if (level == 1) return (uint32_t)(((b + ZZ_L1_GSLOT_BYTES - 1) & ~(uint64_t)(ZZ_L1_GSLOT_BYTES - 1)) + ZZ_L1_GSLOT_BYTES);   // + the packet's hand-over slots, aligned to their size
-#endif
     return (uint32_t)((b + 15) & ~15ull);
 }
 

@@ -88,76 +88,6 @@ __device__ __forceinline__ uint32_t ring_finish(bitring& r)
     return bytes;
 }
 
-// ---- the same packer without LDS (level 1, ten workgroups per CU: the hash table takes the CU's LDS to the byte) -------------
-// Fragments never overlap, so the OR of the fragments that fall into one output word is their SUM, and the sum over a run of
-// lanes is a difference of prefix sums: one DPP scan over the fragments' low halves (each shifted to its place in its word),
-// and the last lane of every word's run holds the word -- minus the prefix of the run before, which it fetches with one
-// ds_bpermute (an LDS-crossbar instruction that needs no LDS memory), plus what the run before spilled over the word boundary.
-// Bits that do not fill a word yet ride along in a register.
-struct regpack {
-    uint32_t* out32;     // next word to be stored
-    uint32_t carry;      // the unfinished word (uniform), its low `cbits` bits valid
-    uint32_t cbits;      // 0..31
-    uint32_t words;      // words stored so far
-};
-__device__ __forceinline__ void pack_init(regpack& r, uint8_t* out)
-{
-    r.out32 = (uint32_t*)out; r.carry = 0; r.cbits = 0; r.words = 0;
-}
-// every lane appends `nb` bits (0 = nothing; nb <= 31, value already masked) in lane order
-__device__ __forceinline__ void pack_append(regpack& r, uint32_t bits, uint32_t nb)
-{
-    const int lane = lane_id();
-    const uint32_t incl = wave_scan_incl(nb);
-    const uint32_t total = readlane(incl, 63);
-    const uint32_t a = r.cbits + incl - nb;                 // where this fragment starts, in bits from the carry word's bit 0
-    const uint32_t wi = a >> 5;
-    const uint64_t v = (uint64_t)bits << (a & 31u);
-    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    const bool last = ((a + nb) >> 5) != wi || lane == 63;  // the next fragment starts in another word
-    const uint32_t S = wave_scan_incl(lo);
-    const uint32_t X = S - hi;                              // what the next run subtracts: my prefix, less what I spill into its word
-    const uint64_t m = ballot(last);
-    const uint64_t below = m & ((1ull << lane) - 1);
-    const int p = 63 - __builtin_clzll(below | 1ull);       // the last lane of the run before mine (lane 0 where there is none: unused)
-    const uint32_t Xp = (uint32_t)__builtin_amdgcn_ds_bpermute(p << 2, (int)X);
-    const uint32_t val = S - (below ? Xp : 0u - r.carry);   // the first run continues the carried word
-    const uint32_t end = r.cbits + total, nfull = end >> 5;
-    if (last && wi < nfull) r.out32[wi] = val;
-    const uint32_t wi63 = readlane(wi, 63), val63 = readlane(val, 63), hi63 = readlane(hi, 63);
-    r.carry = wi63 == nfull ? val63 : hi63;                 // (lane 63 closes the last run: its word is full, or it is the new carry)
-    r.cbits = end & 31u;
-    r.out32 += nfull;
-    r.words += nfull;
-}
-__device__ __forceinline__ void pack_append_uniform(regpack& r, uint32_t bits, uint32_t nb)   // nb <= 32
-{
-    // scalar: the new bits go on top of the carry
-    const uint64_t v = (uint64_t)r.carry | ((uint64_t)bits << r.cbits);
-    const uint32_t end = r.cbits + nb;
-    if (end >= 32) {
-        if (lane_id() == 0) r.out32[0] = (uint32_t)v;
-        r.out32 += 1; r.words += 1;
-        r.carry = (uint32_t)(v >> 32);
-    } else r.carry = (uint32_t)v;
-    r.cbits = end & 31u;
-}
-__device__ __forceinline__ void pack_pad_to_byte(regpack& r)   // outputbitstream.h:100-103
-{
-    r.cbits = (r.cbits + 7u) & ~7u;
-    if (r.cbits == 32) {
-        if (lane_id() == 0) r.out32[0] = r.carry;
-        r.out32 += 1; r.words += 1; r.carry = 0; r.cbits = 0;
-    }
-}
-// outputbitstream.h:105-124 Flush; returns the stream length in bytes (the last partial word is stored whole)
-__device__ __forceinline__ uint32_t pack_finish(regpack& r)
-{
-    pack_pad_to_byte(r);
-    if (r.cbits && lane_id() == 0) r.out32[0] = r.carry;
-    return r.words * 4 + (r.cbits >> 3);
-}
-
 // ---- fixed-Huffman and length/distance symbol arithmetic ---------------------------------------------
 // Tables of the reference (luts.cpp, fixedhuffmanluts.cpp) are RFC 1951 3.2.5/3.2.6 data; on the GPU the
 // symbol, extra-bit count and extra value of a length or distance are computed with clz instead of a

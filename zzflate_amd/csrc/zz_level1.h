@@ -296,16 +296,6 @@ __device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lc
     l1_token_bits(tok, bits, nb);
     ring_append(ring, bits, nb);
 }
-__device__ __forceinline__ void l1_emit_tokens(regpack& pk, uint32_t tok)
-{
-#ifdef ZZ_L1_EMIT_NOP
-    (void)pk; (void)tok;                                               // (experiment: what the emitter's work costs the parser)
-#else
-    uint32_t bits, nb;
-    l1_token_bits(tok, bits, nb);
-    pack_append(pk, bits, nb);
-#endif
-}
 
 // TT = uint16_t: packet mode, positions < 32768, every candidate is within reach.
 // TT = uint32_t: the sequential whole-buffer stream (threaded=false, one block for the whole input): positions up
@@ -317,29 +307,6 @@ __device__ __forceinline__ void l1_emit_tokens(regpack& pk, uint32_t tok)
 // not polling: a polling emitter with an LDS queue was measured 6 % slower) and the parser never stalls.
 // `tokbuf` is the buffer; `ring` and `lcodes` are not touched.
 #define ZZ_L1_TOKSLOT 64u      // 64 tokens; two slots, 512 bytes, 512-byte aligned: slot = byte address ^ 0x100
-#ifdef ZZ_L1_TENWG
-// hand-over slots in global memory: ZZ_L1_GSLOTS slots of 256 bytes, aligned to their total size: the next slot is an add
-// inside the low address bits
-#if ZZ_L1_TENWG >= 2
-#define ZZ_L1_GSLOTS 4u
-#else
-#define ZZ_L1_GSLOTS 2u
-#endif
-#define ZZ_L1_GSLOT_BYTES (ZZ_L1_GSLOTS * 256u)
-// (explicitly global: through a generic pointer these would be FLAT instructions, which count on the LDS counter as well --
-// every wait for an LDS result would then wait for the token store's trip to the L2)
-typedef __attribute__((address_space(1))) uint32_t glb_u32;
-__device__ __forceinline__ void l1_gslot_store(uint32_t* p, uint32_t v) { *(glb_u32*)(uintptr_t)p = v; }
-__device__ __forceinline__ uint32_t l1_gslot_load(const uint32_t* p)
-{
-    return __hip_atomic_load((const glb_u32*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from the L2, where the parser's store is
-}
-template <typename PT> __device__ __forceinline__ PT* l1_next_gslot(PT* p)
-{
-    const uintptr_t a = (uintptr_t)p;
-    return (PT*)((a & ~(uintptr_t)(ZZ_L1_GSLOT_BYTES - 1)) | ((a + 0x100u) & (ZZ_L1_GSLOT_BYTES - 1)));
-}
-#endif
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ lds_u32* lds_flip_slot(lds_u32* p) { return (lds_u32*)(size_t)((uint32_t)(size_t)p ^ 0x100u); }
 __device__ __forceinline__ void l1_group_barrier()
@@ -372,16 +339,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
     uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position
     if (MASKED) { if (start + (uint32_t)lane < n) ld128<SAFE>(src + start + lane, end, w, w2); }
     else ld128<SAFE>(src + (start + (uint32_t)lane < n ? start + (uint32_t)lane : n - 1), end, w, w2);
-#ifdef ZZ_L1_TENWG
-    // Ten workgroups per CU: the hash table takes a workgroup's whole LDS share (16 KiB of 160), so the hand-over slots live
-    // in global memory (two slots of 256 bytes behind the packet's output slot, 512-byte aligned: the other slot = address ^
-    // 0x100). A group's tokens are stored at its end; the barrier that releases them sits behind the next group's wait for
-    // its candidate bytes -- vector memory operations of a wave retire in order, so the store has reached the L2 by then --
-    // and the emitter reads them from the L2 (agent scope).
-    uint32_t* slot = SPLIT ? tokbuf + lane : nullptr;
-#else
     lds_u32* slot = SPLIT ? (lds_u32*)tokbuf + lane : nullptr;            // this lane's word of the hand-over slot in use
-#endif
     // One group of 64 positions. INTERIOR: every lane holds a position with at least 17 bytes after it (all lanes active,
     // no length can run into the block's end) -- all but the last two groups of a packet; the lane-activity compares,
     // the clamps and their scalar bookkeeping drop out of that copy of the code.
@@ -418,9 +376,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             ld128<SAFE>(src + cur + ZZ_WAVE + lane, end, sA, sA2);
             ld128<SAFE>(src + cur + ZZ_WAVE + 16 + lane, end, sB, sB2);
         }
-#if !defined(ZZ_L1_TENWG) && !defined(ZZ_L1_BARRIER_LATE)
         if (SPLIT) l1_group_barrier();                                  // second half of the previous group's hand-over
-#endif
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
         if (tact) rb = T[h];                                            // the slot holds whichever lane wrote last
@@ -462,20 +418,6 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_DRAIN();
         ZZ_T(4);
         const uint64_t x = w ^ wc;                                      // (only looked at where there is a candidate)
-#ifdef ZZ_L1_BARRIER_LATE
-        if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :: "v"((uint32_t)x) : "memory");     // (experiment)
-#endif
-#ifdef ZZ_L1_TENWG
-        // second half of the previous group's hand-over: the candidate bytes are here, so the token store issued before
-        // their load has landed (the operand ties the barrier to that wait)
-        if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :: "v"((uint32_t)x) : "memory");
-#if ZZ_L1_TENWG >= 3
-        // ... and only now do the previous group's tokens leave: a store waits in the same in-order queue as the loads, and
-        // issued at the end of its group it stood in front of this group's candidate load, whose wait then paid for the
-        // store's trip to the L2. From here it has a whole group's time. (The first group stores an empty slot.)
-        if (SPLIT) { l1_gslot_store(slot, ptok); slot = l1_next_gslot(slot); }
-#endif
-#endif
         uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
         if (!old) la = 0;
         info |= la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la;
@@ -663,15 +605,8 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         if (SPLIT) {
             // hand-over, first half: the tokens go to the slot now; the barrier that releases them to the emitter
             // sits in the next trip, behind the wait for the table read that trip needs anyway
-#if ZZ_L1_TENWG >= 3
-            // (stored by the next group, see there)
-#elif defined(ZZ_L1_TENWG)
-            l1_gslot_store(slot, ptok);
-            slot = l1_next_gslot(slot);
-#else
             *slot = ptok;
             slot = lds_flip_slot(slot);
-#endif
         }
         if (sizeof(TT) == 4 && ring.flushed >= (1u << 24)) {
             // long streams: slide the ring's origin (by a multiple of the ring size, so slots keep their meaning)
@@ -690,22 +625,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
     while (cur < n) group(std::false_type{});
     if (!SPLIT) l1_emit_tokens(ring, lcodes, ptok);
     else {
-#if ZZ_L1_TENWG >= 3
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        l1_group_barrier();                                             // the last but one group's hand-over
-        l1_gslot_store(slot, ptok); slot = l1_next_gslot(slot);         // the last group's tokens
-#endif
-#ifdef ZZ_L1_TENWG
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the last group's tokens are in the L2
-#endif
         if (!flagged) {         // a long match ended the packet inside an interior group: an empty group carries the flag
             l1_group_barrier();
-#ifdef ZZ_L1_TENWG
-            l1_gslot_store(slot, ZZ_TOK_LAST);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             *slot = ZZ_TOK_LAST;
-#endif
         }
         l1_group_barrier();                                             // the last group's hand-over
     }
@@ -715,39 +637,6 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
 // The other half of SPLIT: Huffman-codes and appends group after group (fixed codes computed, no table in LDS).
 // It reads slot g & 1 into registers right after barrier g; the parser overwrites that slot only after barrier
 // g + 1, which this wave reaches after the read.
-#ifdef ZZ_L1_TENWG
-__device__ __forceinline__ void l1_emitter(regpack& pk, const uint32_t* tokbuf)
-{
-    const uint32_t* slot = tokbuf + lane_id();
-    l1_group_barrier();                                                  // the parser's barrier in its first group
-#if ZZ_L1_TENWG >= 2
-    // the next group's tokens travel from the L2 while this group's are coded: four slots, so that the parser is two barriers
-    // away from a slot whose load may still be in flight
-    l1_group_barrier();
-    uint32_t tok = l1_gslot_load(slot);
-    for (;;) {
-        slot = l1_next_gslot(slot);
-        const bool lastg = (uniform(tok) & ZZ_TOK_LAST) != 0;            // (waits for the load; lane 0 of a group always holds a token)
-        uint32_t tokn = 0;
-        if (!lastg) {
-            l1_group_barrier();
-            tokn = l1_gslot_load(slot);
-        }
-        l1_emit_tokens(pk, tok & ~ZZ_TOK_LAST);
-        if (lastg) break;
-        tok = tokn;
-    }
-#else
-    for (;;) {
-        l1_group_barrier();
-        const uint32_t tok = l1_gslot_load(slot);
-        slot = l1_next_gslot(slot);
-        l1_emit_tokens(pk, tok & ~ZZ_TOK_LAST);
-        if (uniform(tok) & ZZ_TOK_LAST) break;                           // (lane 0 of a group always holds a token)
-    }
-#endif
-}
-#endif
 __device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf)
 {
     const lds_u32* slot = (const lds_u32*)tokbuf + lane_id();
@@ -879,68 +768,11 @@ __device__ __forceinline__ void l1_packet_emitter(const zz_packet_params& P, uin
     }
 }
 
-#ifdef ZZ_L1_TENWG
-// ---- emitter without LDS (ZZ_L1_TENWG) ------------------------------------------------------------------------------------
-__device__ __forceinline__ void l1_packet_emitter_tenwg(const zz_packet_params& P, uint32_t k, const uint32_t* tokbuf)
-{
-    const int lane = lane_id();
-    const l1_pk q = l1_packet_of(P, k);
-#ifdef ZZ_L1_EMIT_PRIO
-    __builtin_amdgcn_s_setprio(ZZ_L1_EMIT_PRIO);
-#endif
-    regpack ring;
-    pack_init(ring, q.out);
-    if (P.cks_kind == ZZ_CKS_ADLER) {     // while the parser works on its first groups
-        zz_cks c = wave_adler(q.src, q.len);
-        if (lane == 0) P.cks[k] = c;
-    }
-    if (q.n > 0) {
-        // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
-        pack_append_uniform(ring, (q.is_final ? 1u : 0u) | (1u << 1), 3);
-        l1_emitter(ring, tokbuf);
-        // EOB: codes_f[256] = 7 zero bits (encoder.cpp:371)
-        pack_append_uniform(ring, 0, 7);
-    }
-    if (!q.is_final) {
-        // SetLevel(0); AddData(e-1, e): one stored byte = byte alignment (zzflate.cpp:118-120,
-        // encoder.cpp:482-502): BFINAL=0 BTYPE=00, pad, LEN=1, NLEN=0xFFFE, the byte
-        pack_append_uniform(ring, 0, 3);
-        pack_pad_to_byte(ring);
-        pack_append_uniform(ring, 0xFFFE0001u, 32);
-        pack_append_uniform(ring, q.src[q.len - 1], 8);
-    } else if (q.n == 0) {
-        // empty final packet (only for empty input): one empty fixed block (D8 divergence, documented)
-        pack_append_uniform(ring, 1u | (1u << 1), 3);
-        pack_append_uniform(ring, 0, 7);
-    }
-    const uint32_t bytes = pack_finish(ring);
-    if (lane == 0) {
-        P.sizes[k] = bytes;
-        if (bytes > P.slot_stride) atomicOr(P.err, 1u);
-    }
-}
-
-#endif
 // One packet per workgroup, in index order: the hardware dispatcher hands the next packet to whichever CU has room.
 // (Measured and rejected, profiles/README.md: persistent workgroups -- values invariant across packets get hoisted out
 // of the packet loop and live through the group loop, 95 VGPRs instead of 46 --; a second kind of workgroup with its
 // hash table in global memory to fill the wave slots the LDS limit leaves free -- 4x slower per packet: every table
 // access moves a 64-byte sector for two bytes.)
-#ifdef ZZ_L1_TENWG
-// where a packet's hand-over slots live: the last bytes of its output slot (the stride is a multiple of their size)
-__device__ __forceinline__ uint32_t* l1_global_tokbuf(const zz_packet_params& P, uint32_t k)
-{
-    return (uint32_t*)(P.slots + (uint64_t)k * P.slot_stride + (P.slot_stride - ZZ_L1_GSLOT_BYTES));
-}
-__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
-{
-    // the table and nothing else: 16,384 bytes, TEN workgroups share a CU's 160 KiB
-    __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
-    const uint32_t k = blockIdx.x;
-    if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<0>(P, k, T, l1_global_tokbuf(P, k));
-    else l1_packet_emitter_tenwg(P, k, l1_global_tokbuf(P, k));
-}
-#else
 __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
 {
     // table + ring + token slots = 17,408 bytes <= 17,920 = 35 LDS granules: NINE workgroups share a CU
@@ -951,17 +783,7 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
     if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<0>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
 }
-#endif
 // the same with a warm window (P.warm > 0)
-#ifdef ZZ_L1_TENWG
-__global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1w(zz_packet_params P)
-{
-    __shared__ uint16_t T[ZZ_HASH_SIZE];          // position + 1 + 32768; 0 = empty
-    const uint32_t k = blockIdx.x;
-    if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<32768u>(P, k, T, l1_global_tokbuf(P, k));
-    else l1_packet_emitter_tenwg(P, k, l1_global_tokbuf(P, k));
-}
-#else
 __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1w(zz_packet_params P)
 {
     __shared__ uint16_t T[ZZ_HASH_SIZE];          // position + 1 + 32768; 0 = empty
@@ -971,7 +793,6 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1w(zz_packet_params P
     if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<32768u>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
 }
-#endif
 
 // The sequential whole-buffer stream of the reference (threaded=false: zzflate.cpp:84-95, one Encoder over the
 // whole input) at level 1: AddData (encoder.cpp:539-552) calls WriteBlockFixedHuff until the input is used up, and every
