@@ -424,7 +424,7 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/collect_profiles.sh; counters
         # cannot be read inside this run). profiles/traffic.json records which sources it was measured on: it is only
         # reported while those are the sources this run was built from.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, insts = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -436,11 +436,24 @@ def main():
                     hsh.update(f.encode()); hsh.update(open(os.path.join(cdir, f), "rb").read())
                 if tj.get("source_sha256") == hsh.hexdigest():
                     traffic = tj.get(f"level{args.level}_{args.gen}_{args.mib}MiB")
+                    insts = tj.get(f"instructions_level{args.level}_{args.gen}_{args.mib}MiB")
                     traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')}"
                 else:
                     traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')} is stale (kernel sources changed since): not reported"
             except Exception:
                 traffic = None
+        # The bound that applies to levels >= 1 is not HBM but instruction issue (SURVEY.md hard part 5): a
+        # wavefront issues at most one instruction per ~5 cycles (tools/ubench_valu.hip), and the LDS hash table admits 9
+        # workgroups of 2 wavefronts per CU. issue.bound_ms = the kernel's wave-level instructions (SQ_INSTS_*, from the same
+        # profile pass as `traffic`) x 5 cycles / (resident wavefronts x clock): what the kernel would take if every resident
+        # wavefront issued flat out; frac = bound_ms / kernel_ms.
+        issue = None
+        if insts and kms > 0 and args.level >= 1:
+            resident = 256 * (8 if args.level >= 4 else 9) * 2
+            cpi, ghz = 5.0, 2.4
+            bound_ms = insts * cpi / (resident * ghz * 1e9) * 1e3
+            issue = {"bound": "issue", "instructions": insts, "cycles_per_instruction": cpi, "resident_wavefronts": resident,
+                     "clock_ghz": ghz, "bound_ms": round(bound_ms, 3), "frac": round(bound_ms / kms, 4)}
         line = {
             "metric": "input GB/s compressed (whole node) + ratio, level 1, 1/2/4/8 MI355X",
             "value": round(total_n * args.steps / dt / 1e9, 3),
@@ -468,7 +481,7 @@ def main():
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "issue": issue,
             },
             "cpu_baseline": cpu,
             "check": check,

@@ -61,6 +61,13 @@ def main():
     traffic["level1_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l1")
     traffic["level2_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l2_t")
     traffic["level0_random_1024MiB"] = t("fetch_l0", "write_l0", "zz::k_encode_l0")
+    # wave-level instructions per launch (SQ_INSTS_*): what the issue-rate bound in bench.py's roofline is computed from
+    def insts(run, kern):
+        c = out.get(run, {}).get(kern, {})
+        keys = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")
+        return int(sum(c[k] for k in keys)) if all(k in c for k in keys) else None
+    traffic["instructions_level1_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l1")
+    traffic["instructions_level2_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l2_t")
     traffic["git_sha"] = a.git_sha
     traffic["source_sha256"] = source_hash()
     json.dump(traffic, open(os.path.join(a.dest, "traffic.json"), "w"), indent=1)

@@ -303,6 +303,10 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
 
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));   // the CRC-32 pass of the gzip container is part of the timed work
         if (cks_kind == ZZ_CKS_CRC) {
+            // (Round 3 ran this pass BESIDE the encode kernel on a second stream, in front of it or behind it, with 256..2048
+            // workgroups: 96.3-96.7 GB/s against 95.9 on 1 GiB of log lines at level 1, and slower at level 2 -- its LDS table
+            // lookups and VALU work come out of what the encode kernel's waiting parsers leave each other. Not worth a
+            // second stream: profiles/README.md.)
             uint32_t g = npk < 2048 ? npk : 2048;   // persistent: table + shift constants are built once per block
             hipLaunchKernelGGL(k_crc32_packets, dim3(g), dim3(ZZ_CRC_THREADS), 0, st, pp);
             pp.cks_kind = ZZ_CKS_NONE;   // the encode kernel must not overwrite the CRC partials

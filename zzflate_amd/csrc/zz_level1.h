@@ -376,7 +376,6 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             ld128<SAFE>(src + cur + ZZ_WAVE + lane, end, sA, sA2);
             ld128<SAFE>(src + cur + ZZ_WAVE + 16 + lane, end, sB, sB2);
         }
-        if (SPLIT) l1_group_barrier();                                  // second half of the previous group's hand-over
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
         if (tact) rb = T[h];                                            // the slot holds whichever lane wrote last
@@ -418,6 +417,10 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_DRAIN();
         ZZ_T(4);
         const uint64_t x = w ^ wc;                                      // (only looked at where there is a candidate)
+        // second half of the previous group's hand-over. The barrier sits behind the wait for the candidate bytes (the operand
+        // ties it there): the emitter is released where this wave has just been waiting anyway, +0.4 % over a barrier at the
+        // top of the group (profiles/README.md, round 3)
+        if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :: "v"((uint32_t)x) : "memory");
         uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
         if (!old) la = 0;
         info |= la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la;
@@ -679,6 +682,41 @@ __device__ __forceinline__ l1_pk l1_packet_of(const zz_packet_params& P, uint32_
 // to them (one DEFLATE stream: the window spans packet boundaries). Packets stay independent of each other's parses,
 // so nothing is serialised; the stream is not the reference's threaded stream any more (a separate flag), it is
 // pinned by the oracle's restatement of this very rule and by inflate.
+// Warm window: every position of the W bytes in front of the packet goes into the (empty) table under its key -- the three
+// bytes at position + keyoff --, ascending, so that per hash the HIGHEST position stays; eight groups of 64 positions per trip
+// with their loads issued together (one memory round trip per 512 positions). Lanes of one store that share a hash: store,
+// read back, and store again while a lower position is seen. (Round 3 tried one pass instead -- the six-ballot same-hash sets
+// of zz_wave.h name the highest lane of every set, which stores a second time: 92.6 vs 95.3 GB/s at W = 32 KiB; nearly every
+// group of text has some shared hash, and the sets cost more than the one or two extra rounds of this loop.)
+template <uint32_t BIAS>
+__device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, int32_t W, const uint8_t* end, int keyoff)
+{
+    const int lane = lane_id();
+    for (int32_t g = -W; g < 0; g += 8 * ZZ_WAVE) {
+        uint32_t w4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int32_t pos = g + u * ZZ_WAVE + lane;
+            w4[u] = pos < 0 ? load32_safe(src + pos + keyoff, end) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int32_t pos = g + u * ZZ_WAVE + lane;
+            const uint32_t val = (uint32_t)(pos + 1 + (int32_t)BIAS);
+            const uint32_t hh = calc_hash3(w4[u]);
+            bool pend = pos < 0;
+            while (ballot(pend)) {                                  // lanes of one store that share a hash: the highest stays
+                if (pend) T[hh] = (uint16_t)val;
+                ZZ_WAVE_SYNC();
+                uint32_t rb = 0xFFFFFFFFu;
+                if (pend) rb = T[hh];
+                pend = pend && rb < val;
+                ZZ_WAVE_SYNC();
+            }
+        }
+    }
+}
+
 template <uint32_t BIAS>
 __device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf)
 {
@@ -692,32 +730,7 @@ __device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint
     ZZ_WAVE_SYNC();
     if (BIAS) {
         const uint64_t before = P.halo + q.off;                       // input bytes of this stream in front of the packet
-        const int32_t W = (int32_t)(before < P.warm ? before : P.warm);
-        // ascending, so that later positions overwrite earlier ones; eight groups of 64 positions per trip with their
-        // loads issued together (one memory round trip per 512 positions instead of one per 64)
-        for (int32_t g = -W; g < 0; g += 8 * ZZ_WAVE) {
-            uint32_t w4[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int32_t pos = g + u * ZZ_WAVE + lane;
-                w4[u] = pos < 0 ? load32_safe(q.src + pos + 1, q.end) : 0u;      // key of position pos: bytes pos+1..pos+3 (encoder.cpp:344)
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int32_t pos = g + u * ZZ_WAVE + lane;
-                const uint32_t val = (uint32_t)(pos + 1 + (int32_t)BIAS);
-                const uint32_t hh = calc_hash3(w4[u]);
-                bool pend = pos < 0;
-                while (ballot(pend)) {                                  // lanes of one store that share a hash: the highest stays
-                    if (pend) T[hh] = (uint16_t)val;
-                    ZZ_WAVE_SYNC();
-                    uint32_t rb = 0xFFFFFFFFu;
-                    if (pend) rb = T[hh];
-                    pend = pend && rb < val;
-                    ZZ_WAVE_SYNC();
-                }
-            }
-        }
+        warm_prehash<BIAS>(T, q.src, (int32_t)(before < P.warm ? before : P.warm), q.end, 1);   // key of a position: bytes pos+1..pos+3 (encoder.cpp:344)
     }
     bitring none;
     none.ring = nullptr; none.out32 = nullptr; none.bitpos = 0; none.flushed = 0;

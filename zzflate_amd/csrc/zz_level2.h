@@ -1111,30 +1111,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
                     // own three bytes (CalcHash(source + j), :388), ascending, per hash the highest stays
-                    const int32_t Wn = (int32_t)(before < P.warm ? before : P.warm);
-                    for (int32_t g = -Wn; g < 0; g += 8 * ZZ_WAVE) {
-                        uint32_t w4[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int32_t pos = g + u * ZZ_WAVE + lane;
-                            w4[u] = pos < 0 ? load32_safe(src + pos, end) : 0u;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int32_t pos = g + u * ZZ_WAVE + lane;
-                            const uint32_t val = (uint32_t)(pos + 1 + (int32_t)BIAS);
-                            const uint32_t hh = calc_hash3(w4[u]);
-                            bool pend = pos < 0;
-                            while (ballot(pend)) {
-                                if (pend) T[hh] = (uint16_t)val;
-                                ZZ_WAVE_SYNC();
-                                uint32_t rb = 0xFFFFFFFFu;
-                                if (pend) rb = T[hh];
-                                pend = pend && rb < val;
-                                ZZ_WAVE_SYNC();
-                            }
-                        }
-                    }
+                    warm_prehash<BIAS>(T, src, (int32_t)(before < P.warm ? before : P.warm), end, 0);
                 }
                 // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
