@@ -1,7 +1,7 @@
 // zz_level6.h -- the extended levels 4, 5, 6: bounded hash chains, one-step lazy matching, code lengths
 // by package-merge. NOT in the reference, which has one slot per hash, a greedy parse, a frequency-floor length limiter and
 // rejects level > 3 (encoder.h:41-43,76; encoder.cpp:388-424; huffman.cpp:122-154; zzflate.cpp:201,230-234); what this
-// file must be bit-exact with is the definition in oracle/zzoracle.c ("Extended levels"), which it restates for a wavefront:
+// file must be bit-exact with is the definition of these levels in the oracle, which it restates for a wavefront:
 //
 //   chains   every position q of the window in front of the packet and of the packet itself, up to target = n - 16, is
 //            entered under a 13-bit hash of its FOUR bytes, ascending; the candidates of q are the nearest DEPTH earlier
@@ -193,7 +193,7 @@ __device__ __forceinline__ void l6_match_pass(uint32_t* hb, const uint8_t* src, 
 }
 
 // ---- package-merge, wave-parallel ------------------------------------------------------------------------------------------
-// Optimal code lengths <= maxlen for the symbols with a non-zero count (oracle/zzoracle.c pm_lengths, same list form, same
+// Optimal code lengths <= maxlen for the symbols with a non-zero count (the oracle restates it in the same list form, with the same
 // ties): leaves = those symbols sorted by (count, symbol); list 1 = the leaves; list l+1 = merge(leaves, packages of list l),
 // a leaf first where weights are equal, cut at 2m-2 items; from the last list the first 2m-2 items are taken, from every
 // earlier list two per package taken from its successor; a symbol's length = the number of lists its leaf was taken from. Every
