@@ -12,6 +12,7 @@ L = ctypes.CDLL(lib)
 u64, vp, ci, u32 = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
 h = vp()
 assert L.zz_ctx_create(0, ctypes.byref(h)) == 0
+L.zz_ctx_set_extended_levels(h, 1)
 L.zz_bound.restype = u64
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -39,6 +40,11 @@ if level >= 2:
     for i, nm in enumerate(names):
         print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
     pk = max(1, prof[10])
+    if level >= 4:
+        print("  extended levels (cycles/packet): histogram + scan %.0f | wait for the helper's zero fill %.0f | places %.0f | match pass (in 'token pass' above)" % (
+            prof[6] / pk, prof[7] / pk, prof[8] / pk))
+        print("  total incl. those: %.0f cyc/packet" % ((tot + prof[6] + prof[7] + prof[8]) / pk))
+        sys.exit(0)
     print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f | finish block %.0f" % (
         prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[13] / pk))
     sys.exit(0)

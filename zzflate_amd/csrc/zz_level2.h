@@ -1099,11 +1099,14 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
                 const uint32_t xtarget = l6_target(n);
                 if (W0) l6_histogram_and_scan(T, src, Wn, xtarget);
                 else l6_zero_sorted(xsorted, ZZ_L6_PAD + (uint32_t)Wn + xtarget);
+                if (W0) { ZZ_T(6); }
                 __syncthreads();
+                if (W0) { ZZ_T(7); l6_place_all(T, (uint32_t)(ZZ_L2_LDS_BYTES / 2), hb, src, Wn, xtarget); }
+                else l6_store_places(hb, Wn, xtarget, xsorted, xidx);
+                __syncthreads();                                           // the places are in memory ...
                 if (W0) {
-                    l6_place_all(T, (uint32_t)(ZZ_L2_LDS_BYTES / 2), src, Wn, xtarget, xsorted, xidx);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the places are in memory ...
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and no stale line of the previous packet's is in the L1
+                    ZZ_T(8);
                     if (off + len + 16 > P.n) l6_match_pass<XD ? XD : 1, true>(hb, src, end, n, xsorted, xidx);
                     else l6_match_pass<XD ? XD : 1, false>(hb, src, end, n, xsorted, xidx);
                 }

@@ -53,15 +53,15 @@ __device__ __forceinline__ void l6_histogram_and_scan(uint16_t* T, const uint8_t
     const int lane = lane_id();
     uint32_t* Tw = (uint32_t*)T;
     const int32_t lo = -W, hi = (int32_t)target;
-    for (int32_t g = lo; g < hi; g += 4 * ZZ_WAVE) {          // four loads in flight per trip
-        uint32_t v[4];
+    for (int32_t g = lo; g < hi; g += 8 * ZZ_WAVE) {          // eight loads in flight per trip
+        uint32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int32_t pos = g + u * ZZ_WAVE + lane;
             v[u] = load32(src + (pos < hi ? pos : lo));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int32_t pos = g + u * ZZ_WAVE + lane;
             const uint32_t h = l6_hash4(v[u]);
             if (pos < hi) atomicAdd(&Tw[h >> 1], 1u << ((h & 1u) << 4));
@@ -88,74 +88,127 @@ __device__ __forceinline__ void l6_histogram_and_scan(uint16_t* T, const uint8_t
 // ---- counting sort, part 2: every position takes its place ----------------------------------------------------------------
 // Blocks of 64 positions, ascending; the positions of a block that share a hash take consecutive places in lane order (the
 // read-back of a lane tag written to the bucket's counter names one lane per set of equal hashes: six ballots give every lane
-// its set, zz_wave.h). sorted[PAD + place] = position + BIAS; idx[q] = place for the packet's own positions.
-__device__ __forceinline__ void l6_place_all(uint16_t* T, uint32_t spare, const uint8_t* src, int32_t W, uint32_t target,
-                                             uint16_t* sorted, uint16_t* idx)
+// its set, zz_wave.h). The parsing wavefront only works the counters: the places of a block go to the helper wavefront
+// through an LDS slot (two slots, one s_barrier per block), and the helper does the stores -- sorted[PAD + place] = position +
+// BIAS, idx[q] = place for the packet's own positions. (With the stores on the parser's own memory queue, every wait for its
+// next positions' bytes was a wait for all the scattered two-byte stores before them: 27 % of a level-6 packet.)
+__device__ __forceinline__ uint32_t l6_place_blocks(int32_t W, uint32_t target)
+{
+    return ((((uint32_t)W + 63u) & ~63u) + ((target + 63u) & ~63u)) >> 6;
+}
+__device__ __forceinline__ void l6_place_all(uint16_t* T, uint32_t spare, uint32_t* hb, const uint8_t* src, int32_t W, uint32_t target)
 {
     const int lane = lane_id();
     const uint64_t below_me = (1ull << lane) - 1;
     const int32_t lo = -W, hi = (int32_t)target;
-    // (blocks are aligned to the packet: the first window block may be partial)
-    for (int32_t g = -(int32_t)(((uint32_t)W + 63u) & ~63u); g < hi; g += ZZ_WAVE) {
-        const int32_t pos = g + lane;
-        const bool act = pos >= lo && pos < hi;
-        const uint32_t h = act ? l6_hash4(load32(src + (act ? pos : lo))) : spare;    // lanes without a position share a spare counter
-        const uint32_t old = T[h];
-        T[h] = (uint16_t)lane;
-        ZZ_WAVE_SYNC();
-        const uint32_t rb = T[h];
-        ZZ_WAVE_SYNC();
-        uint32_t place = old, cnt = 1;
-        if (ballot(rb != (uint32_t)lane)) {
-            const uint64_t set = wave_match6(rb);
-            place = old + (uint32_t)__builtin_popcountll(set & below_me);
-            cnt = (uint32_t)__builtin_popcountll(set);
+    uint32_t slotsel = 0;
+    // (blocks are aligned to the packet: the first window block may be partial; four blocks' bytes are requested per trip)
+    for (int32_t g0 = -(int32_t)(((uint32_t)W + 63u) & ~63u); g0 < hi; g0 += 4 * ZZ_WAVE) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t pos = g0 + u * ZZ_WAVE + lane;
+            v[u] = load32(src + ((pos >= lo && pos < hi) ? pos : lo));
         }
-        if (rb == (uint32_t)lane) T[h] = (uint16_t)(old + cnt);          // one lane per set moves the counter on
-        ZZ_WAVE_SYNC();
-        if (act) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t g = g0 + u * ZZ_WAVE;
+            if (g >= hi) break;                                             // (uniform)
+            const int32_t pos = g + lane;
+            const bool act = pos >= lo && pos < hi;
+            const uint32_t h = act ? l6_hash4(v[u]) : spare;                // lanes without a position share a spare counter
+            const uint32_t old = T[h];
+            T[h] = (uint16_t)lane;
+            ZZ_WAVE_SYNC();
+            const uint32_t rb = T[h];
+            ZZ_WAVE_SYNC();
+            uint32_t place = old, cnt = 1;
+            if (ballot(rb != (uint32_t)lane)) {
+                const uint64_t set = wave_match6(rb);
+                place = old + (uint32_t)__builtin_popcountll(set & below_me);
+                cnt = (uint32_t)__builtin_popcountll(set);
+            }
+            if (rb == (uint32_t)lane) T[h] = (uint16_t)(old + cnt);          // one lane per set moves the counter on
+            (hb + slotsel)[lane] = place;
+            slotsel ^= ZZ_L2_HB_WORDS;
+            l2_block_barrier();
+        }
+    }
+}
+// the helper's side: one barrier per block, then the block's stores
+__device__ __forceinline__ void l6_store_places(const uint32_t* hb, int32_t W, uint32_t target, uint16_t* sorted, uint16_t* idx)
+{
+    const int lane = lane_id();
+    const int32_t lo = -W, hi = (int32_t)target;
+    uint32_t slotsel = 0;
+    for (int32_t g = -(int32_t)(((uint32_t)W + 63u) & ~63u); g < hi; g += ZZ_WAVE) {
+        l2_block_barrier();
+        const uint32_t place = (hb + slotsel)[lane];
+        slotsel ^= ZZ_L2_HB_WORDS;
+        const int32_t pos = g + lane;
+        if (pos >= lo && pos < hi) {
             sorted[ZZ_L6_PAD + place] = (uint16_t)(pos + (int32_t)ZZ_L6_BIAS);
             if (pos >= 0) idx[pos] = (uint16_t)place;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // in memory before the other wavefront reads them
 }
 
 // ---- the token pass: best of the chain, lazy evaluation, greedy parse; hands every block's matches to the helper wavefront
 // in the level-2 format (zz_level2.h: ZZ_L2_HB_PACK, one s_barrier per block). ---------------------------------------------
+// Everything up to the parse is parse-independent, so the loads run ahead of their use as a three-stage pipeline: while
+// block b-1 is compared and parsed, the candidates' bytes of block b, the chain of block b+1 and the place of block b+2 are
+// in flight (a block's loads depend on each other: place -> chain -> bytes, three trips to the L2 that would otherwise stand
+// in front of every block).
 template <int DEPTH, bool SAFE>
 __device__ __forceinline__ void l6_match_pass(uint32_t* hb, const uint8_t* src, const uint8_t* end, uint32_t n,
                                               const uint16_t* sorted, const uint16_t* idx)
 {
     const int lane = lane_id();
     const uint32_t target = l6_target(n);
+    const uint32_t nblk = (target + 63u) >> 6;
     uint32_t nextpos = 0;                   // first position the parse has not decided
     uint32_t slotsel = 0;
-    for (uint32_t base = 0; base < target; base += 64) {
-        const uint32_t q = base + (uint32_t)lane;
+    struct chain_t { uint16_t c[DEPTH]; };
+    struct bytes_t { uint64_t w, w2, cw[DEPTH], cw2[DEPTH]; uint32_t dist[DEPTH]; };
+    // stage A: where block b's positions stand in the sorted array
+    auto stageA = [&](uint32_t b) -> uint32_t {
+        const uint32_t q = (b << 6) + (uint32_t)lane;
+        return idx[q < target ? q : 0u];                                    // (lanes past the target: any valid place)
+    };
+    // stage B: the chain -- the DEPTH entries in front of the position's place, nearest last
+    auto stageB = [&](uint32_t place) -> chain_t {
+        chain_t ch;
+        __builtin_memcpy(ch.c, sorted + ZZ_L6_PAD + place - DEPTH, 2 * DEPTH);
+        return ch;
+    };
+    // stage C: 16 bytes at the position and at every candidate
+    auto stageC = [&](uint32_t b, const chain_t& ch) -> bytes_t {
+        bytes_t y;
+        const uint32_t q = (b << 6) + (uint32_t)lane;
         const bool act = q < target;
-        const uint32_t qa = act ? q : 0u;                                  // (lanes past the target read the packet's first bytes)
-        uint64_t w, w2;
-        ld128<false>(src + qa, end, w, w2);                                 // q + 16 <= n: inside the data
-        const uint32_t place = idx[qa];
-        // the chain: DEPTH entries in front of this position's place, nearest last
-        uint16_t ch[DEPTH];
-        __builtin_memcpy(ch, sorted + ZZ_L6_PAD + place - DEPTH, 2 * DEPTH);
-        uint64_t cw[DEPTH], cw2[DEPTH];
-        uint32_t dist[DEPTH];
+        const uint32_t qa = act ? q : 0u;
+        ld128<false>(src + qa, end, y.w, y.w2);                             // q + 16 <= n: inside the data
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {                                   // k = 0: the nearest
-            const int32_t c = (int32_t)ch[DEPTH - 1 - k] - (int32_t)ZZ_L6_BIAS;
+            const int32_t c = (int32_t)ch.c[DEPTH - 1 - k] - (int32_t)ZZ_L6_BIAS;
             const uint32_t d = q - (uint32_t)c;                             // 0 < d < 32768: a candidate
             const bool ok = act && (d - 1u) < 32767u;
-            dist[k] = ok ? d : 0u;
-            ld128<false>(src + (ok ? c : (int32_t)qa), end, cw[k], cw2[k]);
+            y.dist[k] = ok ? d : 0u;
+            ld128<false>(src + (ok ? c : (int32_t)qa), end, y.cw[k], y.cw2[k]);
         }
+        return y;
+    };
+    // stage D: best of the chain, lazy evaluation, the parse, hand-over
+    auto stageD = [&](uint32_t b, const bytes_t& y) {
+        const uint32_t base = b << 6;
+        const uint32_t q = base + (uint32_t)lane;
         uint32_t best = 0, bdist = 0;
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
-            uint32_t len = equal_bits128(w ^ cw[k], w2 ^ cw2[k], 128u) >> 3;
-            if (!dist[k]) len = 0;
-            if (len > best) { best = len; bdist = dist[k]; }
+            uint32_t len = equal_bits128(y.w ^ y.cw[k], y.w2 ^ y.cw2[k], 128u) >> 3;
+            if (!y.dist[k]) len = 0;
+            if (len > best) { best = len; bdist = y.dist[k]; }
         }
         if (best < 4) best = 0;
         // lazy: the next position's length (lane 63 never defers)
@@ -189,6 +242,25 @@ __device__ __forceinline__ void l6_match_pass(uint32_t* hb, const uint8_t* src, 
         slot[66] = (uint32_t)evmask; slot[67] = (uint32_t)(evmask >> 32);     // all of them carry start, length, distance
         slot[68] = 0;
         l2_block_barrier();
+    };
+    if (nblk == 0) return;
+    // prologue: fill the pipeline
+    uint32_t placeA = stageA(0);
+    chain_t chB = stageB(placeA);
+    placeA = stageA(nblk > 1 ? 1u : 0u);
+    bytes_t yC = stageC(0, chB);
+    chB = stageB(placeA);
+    placeA = stageA(nblk > 2 ? 2u : 0u);
+    for (uint32_t b = 0; b < nblk; ++b) {
+        // requests for the blocks behind this one go out first ...
+        bytes_t yN;
+        const bool more = b + 1 < nblk;
+        if (more) yN = stageC(b + 1, chB);
+        chB = stageB(placeA);
+        placeA = stageA(b + 3 < nblk ? b + 3 : 0u);
+        // ... then this block is worked on while they travel
+        stageD(b, yC);
+        if (more) yC = yN;
     }
 }
 
