@@ -140,7 +140,10 @@ def launch_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC): documented by the build/run environment of this project as required for
+        # RCCL and device-memory sharing across processes on this pool's host driver, and exported there already; only set
+        # when the caller's environment does not say otherwise (never overridden). DESIGN.md 6.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst = 0
     try:
@@ -181,6 +184,9 @@ def main():
                     "synchronous zz_encode_device call, and the HIP-event kernel time is the kernel's own. 2: two contexts on two "
                     "streams (zz_encode_device_async / zz_encode_finish), the next step's encode kernel fills the CUs the previous "
                     "one's last packets leave idle; per-kernel event times then include that sharing, so roofline is not reported")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "none"], help="N > 1: 'rccl' (default) = the north star's path, every "
+                    "step's compressed shards are gathered onto rank 0; 'none' = encode only, nothing is exchanged (how the "
+                    "encoders alone scale). The default line carries the encode-only rate too (`exchange.encode_only`)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
@@ -246,6 +252,20 @@ def main():
     shard_b = [shard, torch.empty(cap, dtype=torch.uint8, device="cuda") if multi else None]
     gathered_b = [gathered, torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (multi and rank == 0) else None]
     pending = [None, None]
+    # N > 1, --chunks 1: two contexts on two streams, alternating, so that step i's shard can be enqueued BEFORE step i-1's
+    # size and checksum are exchanged (zz_encode_shard_device_async / zz_encode_shard_finish): the host-side part of the
+    # exchange (all-gather of the triples, reading them, posting the send/recv) then runs under step i's kernels
+    mctx = [ctx, None]
+    mstream = [None, None]
+    if multi:
+        mctx[1] = zz.Context(dev)
+        mctx[1].enable_timing(True)
+        if args.warm:
+            mctx[1].set_warm_window(args.warm)
+        if args.level > 3:
+            mctx[1].set_extended_levels(True)
+        mstream = [torch.cuda.Stream(), torch.cuda.Stream()]
+    enq = [False, False]
     C = max(1, args.chunks) if multi else 1
     assert n % (C * P) == 0, "--mib must split into --chunks packet-aligned pieces"
     pipe = None
@@ -283,6 +303,24 @@ def main():
             state["comp_bytes"] = w
             state["last_lane"] = b
 
+    def post_gather(b):
+        """finish the shard enqueued on pair b and start its exchange: sizes/checksums all-gather + ONE grouped send/recv of
+        the compressed shards to rank 0, left in flight"""
+        if not enq[b]:
+            return
+        from zzflate_amd import sharded
+        enq[b] = False
+        w, cks = mctx[b].finish_shard(fmt)
+        kernel_ms.append(mctx[b].last_kernel_ms())
+        state["last_buf"] = b
+        state["comp_bytes"] = w
+        state["last_cks"] = cks
+        if args.gather == "none":
+            state["out_bytes"] = w * world                  # (nothing assembled: the ratio is this rank's)
+            return
+        xshard = shard_b[b] if backend == "nccl" else shard_b[b][:w].cpu()
+        pending[b] = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b], wait=False)
+
     def step():
         if (not multi):
             b = state.get("step", 0) % len(lanes)
@@ -295,7 +333,6 @@ def main():
                 collect(b)                                  # one call at a time: wait for it, as zz_encode_device does
             return
         elif pipe is None:
-            from zzflate_amd import sharded
             b = state.get("step", 0) & 1
             state["step"] = state.get("step", 0) + 1
             if pending[b] is not None:                      # the gather that used this pair of buffers two steps ago
@@ -303,14 +340,11 @@ def main():
                 pending[b] = None
                 if rank == 0:
                     state["out_bytes"] = tot
-            w, cks = ctx.encode_shard(src, n, shard_b[b], cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
-                                      level=args.level, packet_size=P)
-            # sizes/checksums all-gather + ONE grouped send/recv gather of the compressed shards to rank 0, left in
-            # flight: the next step encodes into the other buffers meanwhile
-            xshard = shard_b[b] if backend == "nccl" else shard_b[b][:w].cpu()
-            pending[b] = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b], wait=False)
-            state["last_buf"] = b
-            state["comp_bytes"] = w
+            mctx[b].encode_shard_async(src, n, shard_b[b], cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
+                                       level=args.level, packet_size=P, stream=mstream[b].cuda_stream)
+            enq[b] = True
+            post_gather(b ^ 1)                              # the previous step's exchange, under this step's kernels
+            return
         else:
             # the shard in C pieces: piece c is on its way to rank 0 (async grouped send/recv) while c+1 is encoded
             pipe.begin()
@@ -330,11 +364,12 @@ def main():
             state["comp_bytes"] = wsum
             kernel_ms.append(kms)
             return
-        kernel_ms.append(ctx.last_kernel_ms())
 
     def barrier():
         for b in range(len(lanes)):                         # every call in flight is finished before the clock is read
             collect(b)
+        for b in (0, 1):                                    # the last shard enqueued: finish it, exchange it
+            post_gather(b)
         for b in (0, 1):                                    # every gather has landed before the clock is read
             if pending[b] is not None:
                 tot = pending[b].wait()
@@ -365,7 +400,45 @@ def main():
     check = {}
     torch.cuda.synchronize()
     tv = time.perf_counter()
-    vctx = lanes[state.get("last_lane", 0)]["ctx"] if (not multi) else ctx     # the context of the last step
+    # ---- N > 1: what the exchange costs, measured apart from the overlapped run above (untimed for `value`) ------------
+    # encode_only: the same steps with nothing exchanged; gather_ms_serial: the exchange of the last step's shards on its own,
+    # start to landed, nothing else running; bytes_into_rank0: what rank 0's inbound links carry per step. With these a
+    # scaling run can tell "the encoders do not scale" from "rank 0's links are full" (DESIGN.md 6).
+    exchange = None
+    if multi and pipe is None and args.gather == "rccl":
+        from zzflate_amd import sharded
+        k2 = max(2, min(args.steps, 5))
+        args.gather = "none"
+        step(); barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        barrier()
+        d1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(d1, op=dist.ReduceOp.MAX)
+        args.gather = "rccl"
+        b = state["last_buf"]
+        w, cks = state["comp_bytes"], state["last_cks"]
+        xshard = shard_b[b] if backend == "nccl" else shard_b[b][:w].cpu()
+        gms, tot = [], None
+        for _ in range(k2 + 1):
+            dist.barrier(); torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            tot = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b], wait=True)
+            torch.cuda.synchronize()
+            gms.append((time.perf_counter() - t2) * 1e3)
+        g1 = torch.tensor([sum(gms[1:]) / k2], dtype=torch.float64, device="cuda")      # (the first one warms the connections up)
+        dist.all_reduce(g1, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            state["out_bytes"] = tot
+            hl_, tl_ = {0: (2, 4), 1: (10, 8), 2: (0, 0)}[fmt]
+            inbound = tot - hl_ - tl_ - w
+            e_ms = float(d1.item()) / k2 * 1e3
+            exchange = {"gather": "rccl" if backend == "nccl" else backend,
+                        "encode_only": {"value": round(total_n / (e_ms * 1e-3) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(e_ms, 3), "steps": k2},
+                        "gather_ms_serial": round(float(g1.item()), 3), "bytes_into_rank0_per_step": inbound,
+                        "inbound_GBps_serial": round(inbound / (float(g1.item()) * 1e-3) / 1e9, 2) if inbound else 0.0}
+    vctx = lanes[state.get("last_lane", 0)]["ctx"] if (not multi) else (mctx[state.get("last_buf", 0)] if pipe is None else ctx)   # the context of the last step
     bad, first_bad = vctx.verify_last()
     tv = time.perf_counter() - tv
     if multi:
@@ -375,10 +448,16 @@ def main():
     check["device_inflate"] = {"packets": ((n + P - 1) // P) * world, "bad": bad, "seconds_rank0": round(tv, 3)}
     if rank == 0:
         import zlib
-        out_t = lanes[state.get("last_lane", 0)]["dst"] if (not multi) else gathered_b[state.get("last_buf", 0)]
-        k = min(state["out_bytes"], 96 << 20)
+        if multi and args.gather == "none":                 # nothing was assembled: rank 0's own shard, raw DEFLATE
+            out_t = shard_b[state.get("last_buf", 0)]
+            k = min(state["comp_bytes"], 96 << 20)
+            wb = -15
+        else:
+            out_t = lanes[state.get("last_lane", 0)]["dst"] if (not multi) else gathered_b[state.get("last_buf", 0)]
+            k = min(state["out_bytes"], 96 << 20)
+            wb = {0: 15, 1: 31, 2: -15}[fmt]
         head = out_t[:k].cpu().numpy().tobytes()
-        o = zlib.decompressobj({0: 15, 1: 31, 2: -15}[fmt])
+        o = zlib.decompressobj(wb)
         try:
             dec = o.decompress(head, 64 << 20)
         except zlib.error:            # an invalid stream is reported in the line (inflate_prefix_ok false), not as a crash
@@ -472,10 +551,11 @@ def main():
             "config": {
                 "workload": f"{args.mib} MiB synthetic {args.gen} per GPU (zz_generate_device kind={args.gen}, seed "
                             f"{SEEDS[args.gen]:#x}), level {args.level}, {args.format} container, {P}-byte packets, "
-                            f"input and output resident in HBM" + ((", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if multi else ""),
+                            f"input and output resident in HBM" + ((", nothing exchanged (--gather none)" if args.gather == "none" else ", shards gathered to rank 0 over RCCL" + (f" in {C} overlapped pieces" if C > 1 else ", each step's gather in flight under the next step's encoding")) if multi else ""),
                 "level": args.level, "packet_size": P, "bytes_per_gpu": n, "format": args.format, "warm_window": args.warm,
             },
             "calls_in_flight": len(lanes) if (not multi) else None,
+            "exchange": exchange if multi else None,
             "roofline": {
                 "bound": "hbm", "kernel": "k_encode_l2_t" if args.level >= 2 else f"k_encode_l{args.level}",
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,7 +1,7 @@
 """BASELINE.json's per-GPU configuration sizes under test (one MI355X holds every single-GPU-sized piece):
   C3: 8 GiB uniform-random bytes at levels 0 (stored), 1 (expands 5.5 %) and 2 (stored fallback);
-  C4: one rank's 8 GiB shard of the 64 GiB mixed corpus at level 3 (== 2), with its 64 KiB left halo, through
-      zz_encode_shard_device exactly as a rank of the 8-GPU job runs it;
+  C4: one rank's 8 GiB shard of the 64 GiB mixed corpus at level 3 (== 2) and at the extended level 6 (the config's own
+      wording), with its 64 KiB left halo, through zz_encode_shard_device exactly as a rank of the 8-GPU job runs it;
   C5: one rank's 32 GiB shard of the 256 GiB log lines, gzip container (CRC-32), level 1.
 At these sizes the compacted offsets leave 32 bits. Checks: every packet inflated on the device and compared with its
 input (zz_verify_last_device), size and trailer invariants, a checksum of checksums, and sampled packets -- the first,
@@ -128,6 +128,35 @@ def test_c4_mix_shard_8gib_level3_with_halo(dev, oracle):
             del host
         acc = zz.combine(acc, c, GIB) if i else c
     assert acc == cks3
+
+
+def test_c4_mix_shard_8gib_level6_with_halo(dev, oracle):
+    """configs[3] as BASELINE words it -- "level 6 (longer hash chains)" -- at one rank's size: rank 3's 8 GiB of the mixed corpus
+    with its 64 KiB halo at the extended level 6 (chains of depth 8 over a 32 KiB window, lazy matching, package-merge; beyond
+    the reference, which rejects level > 3). Every packet inflated on the device; sampled packets -- first, around the 4 GiB
+    mark of the output, last -- bit for bit against the oracle's definition, each with the window in front of it; the ratio
+    must beat level 3's by the margin the 1 GiB measurement shows."""
+    torch, ctx = dev
+    n = 8 * GIB
+    seed = 0x5EED0004
+    halo = 65536
+    first = 3 * n
+    buf = torch.empty(halo + n + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate(zz.GEN_MIX, seed, first - halo, buf, halo + n)
+    cap = zz.bound(n, 2, 3, P)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    with pytest.raises(zz.ZzFlateError):                                # off unless switched on (zzflate.cpp:230)
+        ctx.encode_shard(buf.data_ptr() + halo, n, dst, cap, halo=halo, is_last=False, checksum=zz.Format.Zlib, level=6)
+    ctx.set_extended_levels(True)
+    try:
+        w6, cks6 = ctx.encode_shard(buf.data_ptr() + halo, n, dst, cap, halo=halo, is_last=False, checksum=zz.Format.Zlib, level=6)
+        assert ctx.verify_last() == (0, None)
+        check_sampled(torch, ctx, oracle, dst, 0, zz.GEN_MIX, seed, first, n, 6, False, halo)
+        w3, cks3 = ctx.encode_shard(buf.data_ptr() + halo, n, dst, cap, halo=halo, is_last=False, checksum=zz.Format.Zlib, level=3)
+        assert cks6 == cks3                                             # the same input: the same Adler-32 partial
+        assert w6 < 0.94 * w3, (w6, w3)                                 # 1 GiB: 0.4220 against 0.4608
+    finally:
+        ctx.set_extended_levels(False)
 
 
 def test_c5_log_shard_32gib_gzip_level1(dev, oracle):

@@ -132,6 +132,20 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["n_gpus"] == 2 and "gloo" in line["backend"] and "world size 2" in line["backend"]
     assert line["check"]["device_inflate"]["bad"] == 0 and line["check"]["inflate_prefix_ok"]
     assert line["check"]["device_inflate"]["packets"] == 2 * (64 << 20) // 32768
+    # what a scaling run needs to tell encoder scaling from link saturation
+    ex = line["exchange"]
+    assert ex["encode_only"]["value"] > 0 and ex["encode_only"]["ms_per_step"] > 0 and ex["gather_ms_serial"] > 0
+    hl, tl = 2, 4
+    total = round(line["ratio"] * 2 * (64 << 20))
+    assert 0 < ex["bytes_into_rank0_per_step"] < total - hl - tl          # rank 1's shard, and only that
+    assert abs(ex["bytes_into_rank0_per_step"] - (total - hl - tl) / 2) < 0.2 * total
+    # --gather none: the encoders alone
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mib", "64",
+                         "--no-cpu", "--no-extra", "--gather", "none"], env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    l2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l2["exchange"] is None and "nothing exchanged" in l2["config"]["workload"]
+    assert l2["check"]["device_inflate"]["bad"] == 0 and l2["check"]["inflate_prefix_ok"]
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
@@ -150,3 +164,4 @@ def test_rccl_path_with_one_rank(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["backend"].startswith("rccl") and "world size 1" in line["backend"]
     assert line["check"]["device_inflate"]["bad"] == 0 and line["check"]["inflate_prefix_ok"]
+    assert line["exchange"]["bytes_into_rank0_per_step"] == 0 and line["exchange"]["encode_only"]["value"] > 0

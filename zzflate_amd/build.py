@@ -37,5 +37,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+CAREFUL_LIB = os.path.join(HERE, "libzzflate_amd_careful.so")
+
+
+def build_careful(force=False, verbose=False):
+    """A test build with -DZZ_ST_ALWAYS_CAREFUL (the sequential level-2 stream takes its one-position-at-a-time form
+    everywhere, zz_stream2.h): built here, by __graft_entry__.build(), so that the GPU test run does not spend its time in
+    the compiler (tests/test_gpu_sequential.py). Never loaded by the package itself."""
+    if not force and os.path.exists(CAREFUL_LIB) and os.path.getmtime(CAREFUL_LIB) >= _newest_source_mtime():
+        return CAREFUL_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = f"{CAREFUL_LIB}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZZ_ST_ALWAYS_CAREFUL", "-o", tmp] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, CAREFUL_LIB)
+    return CAREFUL_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
