@@ -5,7 +5,7 @@
 # `python3 bench.py ...` directly after `--`. Raw output lands in gpurun_out/prof/<tag>/; tools/summarize_pmc.py
 # turns it into profiles/<tag>_pmc.json, profiles/<tag>_kernel_stats.csv and profiles/traffic.json.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 SHA=${2:-unknown}          # commit of the tree being profiled (the GPU box has no .git: pass $(git rev-parse --short HEAD))
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
