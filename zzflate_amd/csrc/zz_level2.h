@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
                     // own three bytes (CalcHash(source + j), :388), ascending, per hash the highest stays
-                    warm_prehash<BIAS>(T, src, (int32_t)(before < P.warm ? before : P.warm), end, 0);
+                    warm_prehash<BIAS, false>(T, src, (int32_t)(before < P.warm ? before : P.warm), end, 0, (uint32_t)(ZZ_L2_LDS_BYTES / 2));
                 }
                 // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
