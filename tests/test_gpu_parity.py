@@ -595,6 +595,24 @@ def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
         assert enc(d, 1, lvl) == oracle.encode_packets(d, 1, lvl, warm=8192)
 
 
+def test_level2_match_that_overruns_the_batch_and_the_search_region(gpu, oracle):
+    """Regression (found by tools/fuzz_gpu.py, case 7720 of seed 1234, present since round 1): a match that starts in the first
+    16 KiB batch and ends behind n - 258 ends the token pass (encoder.cpp:225-234 leaves its loop with target <= 0); the kernel
+    computed the next batch's length as an unsigned difference and went on probing -- a valid stream, one match too many. The
+    input is period-375 data of 16,866 bytes; neighbouring sizes and periods ride along."""
+    d = zlib.decompress(open(os.path.join(GOLDEN, "cases", "l2_match_overruns_batch_and_search_region.bin.z"), "rb").read())
+    assert len(d) == 16866
+    for lvl in (2, 3):
+        for fmt in (0, 2):
+            assert gpu.encode(d, fmt, lvl) == oracle.encode_packets(d, fmt, lvl), (lvl, fmt)
+    for n in range(16384 + 258 - 40, 16384 + 258 + 300, 7):
+        for per in (259, 300, 375, 511, 700):
+            e = (d[:per] * (n // per + 1))[:n]
+            assert gpu.encode(e, 2, 2) == oracle.encode_packets(e, 2, 2), (n, per)
+    for P in (20000, 17000):
+        assert gpu.encode(d * 3, 2, 3, P) == oracle.encode_packets(d * 3, 2, 3, P), P
+
+
 def test_warm_window_candidates_at_the_very_start_of_the_stream(gpu, oracle):
     """Regression (found by tools/fuzz_gpu.py, case 3690 of seed 9191): with a warm window a candidate may sit in the first
     eight bytes of the STREAM while the packet that probes it has plenty of bytes in front of it, so the "fewer than 8 bytes

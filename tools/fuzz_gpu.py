@@ -89,6 +89,8 @@ for it in range(cases):
         elvl = lvl
         if mode == 2 and rng.random() < 0.4:
             elvl = rng.choice([4, 5, 6]); warm = 0
+        if os.environ.get("ZZ_FUZZ_EXT") == "1":          # every packet-mode case at an extended level (a separate, own random stream)
+            elvl = 4 + (it * 7 + len(d)) % 3; warm = 0
         ctx.set_warm_window(warm)
         ctx.set_extended_levels(elvl > 3)
         cap = zz.bound(len(d), fmt, min(elvl, 3), P)

@@ -23,6 +23,9 @@ if kind == 9:   # real English text: the Canterbury text files tiled (cold table
     base = b"".join(open(os.path.join(ROOT, "tests/golden/corpus", f), "rb").read() for f in ("alice29.txt", "asyoulik.txt", "lcet10.txt", "plrabn12.txt"))
     host = (base * (n // len(base) + 1))[:n]
     src[:n].copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+elif kind in (12, 14):   # random bytes over 2 / 4 symbols (the DNA-like family of the mix is the latter)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    src[:n].copy_(torch.randint(0, kind - 10, (n,), generator=g, device="cuda", dtype=torch.uint8) + 65)
 else:
     L.zz_generate_device(h, ci(kind), u64(0x5EED0002), u64(0), vp(src.data_ptr()), u64(n), vp(0))
 cap = L.zz_bound(u64(n), ci(0), ci(level), u32(32768))

@@ -164,13 +164,21 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
 // literals and the group is done (the caller need not look at E again).
 // FIRST: the group's first entry (pos = 0): the first event comes straight from E. Otherwise: re-entry behind an event
 // the C++ path decided; pos may lie at or beyond 64 (then there is nothing to do).
+// what the walk needs to decide a lane whose candidate is an arbitrary earlier lane of the group (label 7 of the loop)
+struct l1_walk_x {
+    uint32_t hash, wlo, whi;         // per lane: the hash, the first eight bytes at the position
+    uint32_t candbase;               // candidate lane c as a table entry: candbase + c  (= cur + 1 + BIAS + c)
+    uint32_t hardok;                 // 0: leave such lanes to the C++ path (groups at a block's end: lengths need clamping)
+    uint32_t ovlen, ovcand1;         // per lane, in/out: the overrides of the tokens' length and candidate ...
+    uint64_t ovmL, ovmC;             // ... and the lanes that hold one
+};
 template <bool FIRST>
 __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t nact, uint32_t& pos, uint64_t& mst, uint64_t& cov,
-                                             uint64_t& usedB)
+                                             uint64_t& usedB, l1_walk_x& X)
 {
-    uint64_t tmp;
+    uint64_t tmp, tmp2;
     int32_t e, e2;
-    uint32_t inf, len, q;
+    uint32_t inf, len, q, t0, vt;
 #define ZZ_L1_WALK_BODY \
         "9:\n\t" \
         ZZ_L1_HOP("%[e]", "%[e2]", "4f") "s_cbranch_scc0 31f\n\t" \
@@ -209,8 +217,9 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_cbranch_scc1 6f\n\t" \
         "s_bitcmp0_b64 %[cov], %[q]\n\t"            /* visited as a literal? */ \
         "s_cbranch_scc1 6f\n\t" \
-        "s_bitcmp1_b32 %[inf], 18\n\t"              /* skipped, and further lanes share the hash (HARD): leave */ \
-        "s_cbranch_scc1 3f\n\t" \
+        "s_bitcmp1_b32 %[inf], 18\n\t"              /* skipped, and further lanes share the hash (HARD): see 7 */ \
+        "s_cbranch_scc1 7f\n" \
+        "71:\n\t" \
         "s_bitcmp1_b32 %[inf], 19\n\t"              /* skipped: the table's candidate; EXTA: leave */ \
         "s_cbranch_scc1 3f\n\t" \
         "s_and_b32 %[len], %[inf], 31\n\t" \
@@ -228,13 +237,53 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "8:\n\t" \
         "s_add_u32 %[pos], %[e], 1\n\t"             /* a literal after all (encoder.cpp:367) */ \
         "s_cmp_lt_u32 %[pos], 64\n\t" \
-        "s_cbranch_scc1 1b\n" \
+        "s_cbranch_scc1 1b\n\t" \
+        "s_branch 3f\n" \
+        /* The nearest earlier lane with my hash was skipped and the hash has further members: the candidate is the most   */ \
+        /* recent VISITED lane with my hash, else the table's (encoder.cpp:344-346: only probed positions are entered).    */ \
+        /* Round 2 left the loop here for ~67 instructions of C++; on data with few distinct trigrams (4-symbol: 59 GB/s) */ \
+        /* that is most events. Same-hash lanes: one v_cmp against this lane's hash.                                       */ \
+        "7:\n\t" \
+        "s_cmp_eq_u32 %[hardok], 0\n\t"             /* (a packet's last groups: lengths need clamping: C++) */ \
+        "s_cbranch_scc1 3f\n\t" \
+        "v_readlane_b32 %[t0], %[hash], %[e]\n\t" \
+        "v_cmp_eq_u32_e64 %[tmp], %[t0], %[hash]\n\t"  /* lanes with my hash */ \
+        "s_orn2_b64 %[tmp2], %[mst], %[cov]\n\t"    /* visited lanes: match starts and whatever no match covers */ \
+        "s_and_b64 %[tmp], %[tmp], %[tmp2]\n\t" \
+        "s_bfm_b64 %[tmp2], %[e], 0\n\t"            /* lanes below e */ \
+        "s_and_b64 %[tmp], %[tmp], %[tmp2]\n\t" \
+        "s_cbranch_scc0 71b\n\t"                    /* none visited: the table's candidate, as for a lane with one earlier member */ \
+        "s_flbit_i32_b64 %[q], %[tmp]\n\t" \
+        "s_sub_u32 %[q], 63, %[q]\n\t"              /* the most recent of them */ \
+        "v_readlane_b32 %[t0], %[wlo], %[e]\n\t" \
+        "v_readlane_b32 %[len], %[wlo], %[q]\n\t" \
+        "s_xor_b32 %[t0], %[t0], %[len]\n\t" \
+        "s_cbranch_scc1 8b\n\t"                     /* fewer than four bytes agree: a literal (encoder.cpp:356) */ \
+        "v_readlane_b32 %[t0], %[whi], %[e]\n\t" \
+        "v_readlane_b32 %[len], %[whi], %[q]\n\t" \
+        "s_xor_b32 %[t0], %[t0], %[len]\n\t" \
+        "s_cbranch_scc0 3f\n\t"                     /* eight or more: extension, C++ */ \
+        "s_ff1_i32_b32 %[t0], %[t0]\n\t" \
+        "s_lshr_b32 %[t0], %[t0], 3\n\t" \
+        "s_add_u32 %[len], %[t0], 4\n\t"            /* 4..7 bytes */ \
+        "s_lshl_b64 %[tmp2], 1, %[e]\n\t"           /* the token's length and candidate, into the lane that holds it (a select */ \
+        "s_or_b32 %[t0], %[len], 0x8000\n\t"        /* under a one-lane mask: v_writelane would need M0 for the lane number)   */ \
+        "v_mov_b32 %[vt], %[t0]\n\t" \
+        "v_cndmask_b32_e64 %[ovlen], %[ovlen], %[vt], %[tmp2]\n\t" \
+        "s_add_u32 %[t0], %[candbase], %[q]\n\t" \
+        "v_mov_b32 %[vt], %[t0]\n\t" \
+        "v_cndmask_b32_e64 %[ovcand], %[ovcand], %[vt], %[tmp2]\n\t" \
+        "s_bitset1_b64 %[ovmL], %[e]\n\t" \
+        "s_bitset1_b64 %[ovmC], %[e]\n\t" \
+        "s_branch 5b\n" \
         "3:\n\t"
 #define ZZ_L1_WALK_OPERANDS \
         : [pos] "+s"(pos), [mst] "+s"(mst), [cov] "+s"(cov), [usedB] "+s"(usedB), [tmp] "=&s"(tmp), [e] "=&s"(e), [e2] "=&s"(e2), \
-          [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q) \
-        : [E] "s"(E), [info] "v"(info), [nact] "s"(nact) \
-        : "scc"
+          [inf] "=&s"(inf), [len] "=&s"(len), [q] "=&s"(q), [tmp2] "=&s"(tmp2), [t0] "=&s"(t0), [vt] "=&v"(vt), \
+          [ovlen] "+v"(X.ovlen), [ovcand] "+v"(X.ovcand1), [ovmL] "+s"(X.ovmL), [ovmC] "+s"(X.ovmC) \
+        : [E] "s"(E), [info] "v"(info), [nact] "s"(nact), [hash] "v"(X.hash), [wlo] "v"(X.wlo), [whi] "v"(X.whi), \
+          [candbase] "s"(X.candbase), [hardok] "s"(X.hardok) \
+        : "scc", "vcc"
     if (FIRST)
         asm volatile(
             "s_ff1_i32_b64 %[e], %[E]\n\t"              // the group's first event (-1: none)
@@ -444,10 +493,13 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // on this machine (a dependent SALU op ~8 cycles, a taken branch ~40: tools/ubench_scalar.hip), so runs
         // of "simple" matches go through a hand-written 12-instruction loop; everything else drops out to C++.
         uint64_t mst = 0, cov = 0, usedB = 0;    // match-start lanes / lanes covered by matches / matched the in-group candidate
-        uint32_t ovlen = 0, ovcand1 = 0;         // per-lane overrides written for extended / hard events (length | 0x8000) ...
-        uint64_t ovmL = 0, ovmC = 0;             // ... and the lanes that hold one
+        l1_walk_x X;                             // per-lane overrides written for extended / hard events (length | 0x8000), the lanes that hold one
+        X.hash = h; X.wlo = (uint32_t)w; X.whi = (uint32_t)(w >> 32); X.candbase = cur + 1 + BIAS; X.hardok = INTERIOR ? 1u : 0u;
+        X.ovlen = 0; X.ovcand1 = 0; X.ovmL = 0; X.ovmC = 0;
+        uint32_t& ovlen = X.ovlen; uint32_t& ovcand1 = X.ovcand1;
+        uint64_t& ovmL = X.ovmL; uint64_t& ovmC = X.ovmC;
         uint32_t pos = 0;
-        l1_fast_walk<true>(E, info, nact, pos, mst, cov, usedB);
+        l1_fast_walk<true>(E, info, nact, pos, mst, cov, usedB, X);
         while (pos < nact) {
             const int e = (int)pos;                                     // the walk stopped AT an event it cannot decide
             ZZ_C(11, 1);
@@ -498,7 +550,7 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             } else {
                 pos = (uint32_t)e + 1;                                   // a literal after all (encoder.cpp:367)
             }
-            l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB);
+            l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB, X);
         }
         ZZ_T(6);
         // visited lanes: every lane in front of `pos` that no match covers, plus the match starts

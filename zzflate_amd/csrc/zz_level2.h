@@ -811,7 +811,9 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             skipPos = B >= batchEnd ? 0xFFFFFFFFu : batchEnd;
             B = s2 + 1;
             nextProbe = s2 + 1;
-            const uint32_t rest = target - s2;
+            // (a match that overruns the batch AND the search region ends the pass: encoder.cpp:225-234 leaves its loop with
+            // target <= 0 -- found by tools/fuzz_gpu.py, seed 1234: period-375 data of 16,866 bytes got one match too many)
+            const uint32_t rest = target > s2 ? target - s2 : 0u;
             batchEnd = s2 + (rest < ZZ_BATCH_LEN ? rest : ZZ_BATCH_LEN);
         }
         if (base >= 64 && skipPos == 0xFFFFFFFFu && base + 64 <= batchEnd && base + 64 > nextProbe) block(std::true_type{}, base);
