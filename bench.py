@@ -340,6 +340,9 @@ def main():
                 pending[b] = None
                 if rank == 0:
                     state["out_bytes"] = tot
+            # (a request's wait() orders the CURRENT stream behind the transfer; the encode runs on a stream of its own and
+            # must not overwrite the shard buffer while that send may still be reading it)
+            mstream[b].wait_stream(torch.cuda.current_stream())
             mctx[b].encode_shard_async(src, n, shard_b[b], cap, halo=halo, is_last=(rank == world - 1), checksum=fmt,
                                        level=args.level, packet_size=P, stream=mstream[b].cuda_stream)
             enq[b] = True
