@@ -1332,7 +1332,12 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
 // xdepth: 0 = levels 2,3; 2 / 4 / 8 = the extended levels 4 / 5 / 6 (chain depth)
 static inline uint32_t l2_grid(uint32_t npk, int xdepth = 0)
 {
-    const uint32_t resident = 256 * (xdepth ? 8 : 9);      // CUs x workgroups the LDS (xdepth: the register) budget admits
+    // Levels 2,3: what the LDS budget admits. The extended levels are bound by the fabric, not by the CUs (r03 counters: 395 GB
+    // of traffic per GiB of input at 5 TB/s -- their scratch and windows, 350 KiB per resident packet, thrash the L2s): FIVE
+    // resident packets per CU run faster than the eight the registers admit (level 6: 68.3 against 77.7 ms per GiB; 4: 67.9; 3:
+    // 74.5; env ZZFLATE_L6_WG_PER_CU for experiments).
+    static const uint32_t xper = [] { const char* e = getenv("ZZFLATE_L6_WG_PER_CU"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 8 ? v : 5); }();
+    const uint32_t resident = 256 * (xdepth ? xper : 9);
     return npk < resident ? npk : resident;
 }
 static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth)
