@@ -512,7 +512,7 @@ def main():
             extra["level6"] = {"error": str(e)}
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:        # (the CPU leg runs at N = 1 only: the other ranks would wait for it)
         sample_bytes = min(n, 1 << 30)
         # the reference has no level above 3 (zzflate.cpp:201,230): its level 3 is the baseline of the extended levels
         cpu = cpu_baseline(src[:sample_bytes].cpu().numpy().tobytes(), min(args.level, 3), fmt, P)
