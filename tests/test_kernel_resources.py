@@ -1,0 +1,46 @@
+"""What the occupancy arithmetic of DESIGN.md 4 rests on, checked against the compiler (CPU only: hipcc cross-compiles gfx950):
+LDS per workgroup small enough for nine workgroups per CU, registers small enough for the wavefronts those need, no scratch in
+the level-1 kernels, and scratch in the level-2 kernel touched at kernel entry and once per packet only -- never inside the block
+loops (tools/scratch_report.py is the long form; profiles/r03_resource_usage.txt its output)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def report():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scratch_report.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def usage(report, mangled):
+    m = re.search(r"Function Name: %s\n(.*?)\n\n" % re.escape(mangled), report, flags=re.S)
+    assert m, mangled
+    return {k.strip(): v.strip() for k, v in (ln.split(":", 1) for ln in m.group(1).splitlines() if ":" in ln)}
+
+
+def test_level1_kernels_fit_nine_workgroups_per_cu_without_scratch(report):
+    for name in ("_ZN2zz11k_encode_l1E16zz_packet_params", "_ZN2zz12k_encode_l1wE16zz_packet_params"):
+        u = usage(report, name)
+        assert int(u["LDS Size [bytes/block]"]) * 9 <= 160 * 1024          # nine 16 KiB hash tables (+ ring, + slots) per CU
+        assert int(u["VGPRs"]) <= 96 and int(u["ScratchSize [bytes/lane]"]) == 0
+    assert re.search(r"k_encode_l1E16zz_packet_params: 0 scratch_store, 0 scratch_load", report)
+
+
+def test_level2_kernel_scratch_stays_out_of_the_block_loops(report):
+    u = usage(report, "_ZN2zz13k_encode_l2_tILj0ELi0EEEvNS_12zz_l2_paramsE")
+    assert int(u["LDS Size [bytes/block]"]) * 9 <= 160 * 1024 and int(u["VGPRs"]) <= 96
+    m = re.search(r"k_encode_l2_tILj0ELi0EEEvNS_12zz_l2_paramsE: (\d+) scratch_store, (\d+) scratch_load instructions\n((?:  depth .*\n)*)", report)
+    assert m
+    depths = [int(d) for d in re.findall(r"depth (\d+):", m.group(3))]
+    assert depths and max(depths) <= 1, m.group(0)           # kernel entry (0) and the packet loop (1); the block loops are depth >= 2
