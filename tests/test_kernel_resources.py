@@ -38,9 +38,9 @@ def test_level1_kernels_fit_nine_workgroups_per_cu_without_scratch(report):
 
 
 def test_level2_kernel_scratch_stays_out_of_the_block_loops(report):
-    u = usage(report, "_ZN2zz13k_encode_l2_tILj0ELi0EEEvNS_12zz_l2_paramsE")
+    u = usage(report, "_ZN2zz13k_encode_l2_tILj0ELb0EEEvNS_12zz_l2_paramsE")
     assert int(u["LDS Size [bytes/block]"]) * 9 <= 160 * 1024 and int(u["VGPRs"]) <= 96
-    m = re.search(r"k_encode_l2_tILj0ELi0EEEvNS_12zz_l2_paramsE: (\d+) scratch_store, (\d+) scratch_load instructions\n((?:  depth .*\n)*)", report)
+    m = re.search(r"k_encode_l2_tILj0ELb0EEEvNS_12zz_l2_paramsE: (\d+) scratch_store, (\d+) scratch_load instructions\n((?:  depth .*\n)*)", report)
     assert m
     depths = [int(d) for d in re.findall(r"depth (\d+):", m.group(3))]
     assert depths and max(depths) <= 1, m.group(0)           # kernel entry (0) and the packet loop (1); the block loops are depth >= 2

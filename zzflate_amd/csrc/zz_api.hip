@@ -130,7 +130,7 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipMalloc(&c->d_res, sizeof(zz_result)));
         HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
         HIPCHK(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)));          // [0] slot overflow, [1] stream truncated, [2] log entries
-        HIPCHK(hipMalloc(&c->d_work, sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&c->d_work, 16 * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
@@ -177,8 +177,8 @@ extern "C" int zz_debug_occupancy(int level)
 {
     int nb = -1;
     if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
-    else if (level >= 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<32768u, 8>, ZZ_L2_THREADS, 0);
-    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, 0>, ZZ_L2_THREADS, 0);
+    else if (level >= 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<32768u, true>, ZZ_L2_THREADS, 0);
+    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, false>, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
 }
@@ -217,7 +217,7 @@ extern "C" double zz_ctx_last_kernel_ms(zz_ctx* c)
     return ms;
 }
 
-static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride, int xdepth = 0)
+static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride, int xdepth = 0, uint32_t P = 0)
 {
     if (npk > c->npk_cap) {
         (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
@@ -236,7 +236,7 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride,
         }
     }
     if (level >= 2) {
-        uint64_t need = l2_scratch_bytes((uint32_t)npk, xdepth);
+        uint64_t need = l2_scratch_bytes((uint32_t)npk, xdepth, P);
         if (need > c->l2_scratch_cap) {
             (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
             HIPCHK(hipMalloc(&c->l2_scratch, need));
@@ -294,7 +294,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         for (uint32_t i = 0; i < bl; ++i) packed |= (uint64_t)blk[i] << (8 * i);
         hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, d_dst + hl, packed, bl, c->d_res, (uint64_t)bl);
     } else {
-        int rc = ensure_workspace(c, level, npk, stride, xdepth);
+        int rc = ensure_workspace(c, level, npk, stride, xdepth, P);
         if (rc) return rc;
         zz_packet_params pp;
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;

@@ -1000,6 +1000,8 @@ struct zz_l2_params {
     zz_packet_params pk;
     uint8_t* scratch;      // gridDim.x * ZZ_L2_SCRATCH_BYTES
     uint32_t* work;        // packets handed out beyond the first gridDim.x (zero at launch)
+    const uint32_t* m;     // extended levels: k_l6_matches' word per input byte of the packets k0 .. k1-1
+    uint32_t k0, k1;       // the packets of this launch (levels 2,3: all of them)
 };
 
 #define ZZ_L2_THREADS (2 * ZZ_WAVE)
@@ -1013,11 +1015,10 @@ struct zz_l2_params {
 // wavefront 1 keeps the books (matches to scratch, bitmap window, symbol counts, finished blocks to records, the
 // Adler-32 sums), one s_barrier per 64-position block. Afterwards wavefront 0 builds the codes and both emit.
 // BIAS = 32768: the same with a warm window (P.warm bytes in front of every packet are hashed into its table first).
-// XD > 0: the extended levels 4..6 (zz_level6.h) -- chains of depth XD instead of the one-slot table, lazy parse, package-merge
-// code lengths; everything behind the token pass and the code lengths is shared. Eight candidates in flight want more
-// registers: four wavefronts per SIMD instead of five, i.e. eight workgroups per CU.
-template <uint32_t BIAS, int XD = 0>
-__global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2_params Q)
+// XD: the extended levels 4..6 (zz_level6.h) -- the parser walks the per-position matches that k_l6_matches left in Q.m instead
+// of probing a table, and the code lengths come from package-merge; everything else is shared.
+template <uint32_t BIAS, bool XD = false>
+__global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
     // ---- LDS carve-up: 17,840 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
@@ -1061,17 +1062,15 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
     const int lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x >> 6);
     ZZ_PROF_DECL
-    uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * (ZZ_L2_SCRATCH_BYTES + (XD ? ZZ_L6_SCRATCH_BYTES : 0u));
+    uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES;
     uint32_t* tokens = (uint32_t*)my_scratch;                                   // matches in stream order
     uint16_t* recs = (uint16_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 4);            // records in stream order
-    uint16_t* const xsorted = (uint16_t*)(my_scratch + ZZ_L2_SCRATCH_BYTES);    // XD: positions sorted by (hash, position)
-    uint16_t* const xidx = (uint16_t*)(my_scratch + ZZ_L2_SCRATCH_BYTES + ZZ_L6_SORT_BYTES);
 
     // Persistent workgroups: the first packet is the workgroup's index, every further one comes from a counter, so
     // that packets of unequal cost (stored fallback vs. dynamic block) do not leave workgroups idle at the end.
     auto next_packet = [&]() -> uint32_t {
         __syncthreads();                                   // both wavefronts are done with the packet (and with LDS)
-        if (threadIdx.x == 0) ((uint32_t*)covw)[2] = gridDim.x + atomicAdd(Q.work, 1u);
+        if (threadIdx.x == 0) ((uint32_t*)covw)[2] = Q.k0 + gridDim.x + atomicAdd(Q.work, 1u);
         __syncthreads();
         return uniform(((uint32_t*)covw)[2]);
     };
@@ -1093,7 +1092,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
         __syncthreads();       // both wavefronts are done with the previous packet
         if (W0) {
             uint4* z = (uint4*)lds;
-            for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
+            if (!XD) for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
         } else {
             uint32_t* zw = (uint32_t*)covw;
             for (int i = lane; i < 2 * ZZ_L2_WIN * 2 + ZZ_L2_HIST_WORDS; i += ZZ_WAVE) zw[i] = 0;   // window + counters
@@ -1104,22 +1103,11 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
         if (n > 0) {
             // ================= token pass (encoder.cpp:217-248, 375-471) ===========================================
             if (XD) {
-                // the extended levels: counting sort of all positions by hash (histogram + scan here, the array zeroed by
-                // the helper meanwhile), then the chains are one load per position (zz_level6.h)
-                const int32_t Wn = (int32_t)(before < P.warm ? before : P.warm);
-                const uint32_t xtarget = l6_target(n);
-                if (W0) l6_histogram_and_scan(T, src, Wn, xtarget);
-                else l6_zero_sorted(xsorted, ZZ_L6_PAD + (uint32_t)Wn + xtarget);
-                if (W0) { ZZ_T(6); }
-                __syncthreads();
-                if (W0) { ZZ_T(7); l6_place_all(T, (uint32_t)(ZZ_L2_LDS_BYTES / 2), hb, src, Wn, xtarget); }
-                else l6_store_places(hb, Wn, xtarget, xsorted, xidx);
-                __syncthreads();                                           // the places are in memory ...
+                // the extended levels: every position's match is in Q.m already (k_l6_matches, zz_level6.h)
                 if (W0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and no stale line of the previous packet's is in the L1
-                    ZZ_T(8);
-                    if (off + len + 16 > P.n) l6_match_pass<XD ? XD : 1, true>(hb, src, end, n, xsorted, xidx);
-                    else l6_match_pass<XD ? XD : 1, false>(hb, src, end, n, xsorted, xidx);
+                    const uint32_t* mrow = Q.m + (uint64_t)(k - Q.k0) * P.packet_size;
+                    if (off + len + 16 > P.n) l6_parse_pass<true>(hb, src, end, n, mrow);
+                    else l6_parse_pass<false>(hb, src, end, n, mrow);
                 }
             } else if (W0) {
                 if (BIAS) {
@@ -1322,38 +1310,58 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 4 : 5) void k_encode_l2_t(zz_l2
     };
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);      // the parse is the packet's critical path: ahead of the helpers in the issue arbiter
-        for (uint32_t k = blockIdx.x; k < P.npk; k = next_packet()) packet(k, std::true_type());
+        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::true_type());
     } else {
-        for (uint32_t k = blockIdx.x; k < P.npk; k = next_packet()) packet(k, std::false_type());
+        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::false_type());
     }
     ZZ_PROF_FLUSH(P);
 }
 
 // xdepth: 0 = levels 2,3; 2 / 4 / 8 = the extended levels 4 / 5 / 6 (chain depth)
-static inline uint32_t l2_grid(uint32_t npk, int xdepth = 0)
+static inline uint32_t l2_grid(uint32_t npk)
 {
-    // Levels 2,3: what the LDS budget admits. The extended levels are bound by the fabric, not by the CUs (r03 counters: 395 GB
-    // of traffic per GiB of input at 5 TB/s -- their scratch and windows, 350 KiB per resident packet, thrash the L2s): FIVE
-    // resident packets per CU run faster than the eight the registers admit (level 6: 68.3 against 77.7 ms per GiB; 4: 67.9; 3:
-    // 74.5; env ZZFLATE_L6_WG_PER_CU for experiments).
-    static const uint32_t xper = [] { const char* e = getenv("ZZFLATE_L6_WG_PER_CU"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 8 ? v : 5); }();
-    const uint32_t resident = 256 * (xdepth ? xper : 9);
+    const uint32_t resident = 256 * 9;     // what the LDS budget admits
     return npk < resident ? npk : resident;
 }
-static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth)
+// the extended levels go through the input in batches of about 1 GiB: k_l6_matches over a batch's packets (one word per input
+// byte: 4 GiB), then the encode kernel over the same packets
+static inline uint32_t l6_batch_packets(uint32_t npk, uint32_t P)
 {
-    return (uint64_t)l2_grid(npk, xdepth) * (ZZ_L2_SCRATCH_BYTES + (xdepth ? ZZ_L6_SCRATCH_BYTES : 0u));
+    static const uint64_t bytes = [] { const char* e = getenv("ZZFLATE_L6_BATCH_MIB"); const long v = e ? atol(e) : 0; return (uint64_t)(v >= 1 && v <= 65536 ? v : 1024) << 20; }();
+    const uint64_t b = bytes / P ? bytes / P : 1;
+    return (uint32_t)(b < npk ? b : npk);
+}
+static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth, uint32_t P)
+{
+    uint64_t need = (uint64_t)l2_grid(npk) * ZZ_L2_SCRATCH_BYTES;
+    if (xdepth) need += (uint64_t)l6_batch_packets(npk, P) * P * 4u;
+    return need;
 }
 static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st, int xdepth = 0)
 {
-    zz_l2_params q; q.pk = pp; q.scratch = scratch; q.work = work;
-    (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
-    const dim3 g(l2_grid(pp.npk, xdepth)), b(ZZ_L2_THREADS);
-    if (xdepth == 2) hipLaunchKernelGGL((k_encode_l2_t<32768u, 2>), g, b, 0, st, q);
-    else if (xdepth == 4) hipLaunchKernelGGL((k_encode_l2_t<32768u, 4>), g, b, 0, st, q);
-    else if (xdepth == 8) hipLaunchKernelGGL((k_encode_l2_t<32768u, 8>), g, b, 0, st, q);
-    else if (pp.warm) hipLaunchKernelGGL((k_encode_l2_t<32768u, 0>), g, b, 0, st, q);
-    else hipLaunchKernelGGL((k_encode_l2_t<0u, 0>), g, b, 0, st, q);
+    zz_l2_params q; q.pk = pp; q.scratch = scratch; q.work = work; q.m = nullptr; q.k0 = 0; q.k1 = pp.npk;
+    if (!xdepth) {
+        (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
+        const dim3 g(l2_grid(pp.npk)), b(ZZ_L2_THREADS);
+        if (pp.warm) hipLaunchKernelGGL((k_encode_l2_t<32768u, false>), g, b, 0, st, q);
+        else hipLaunchKernelGGL((k_encode_l2_t<0u, false>), g, b, 0, st, q);
+        return;
+    }
+    uint32_t* const m = (uint32_t*)(scratch + (uint64_t)l2_grid(pp.npk) * ZZ_L2_SCRATCH_BYTES);
+    const uint32_t batch = l6_batch_packets(pp.npk, pp.packet_size);
+    static const uint32_t mgrid = [] { const char* e = getenv("ZZFLATE_L6_MATCH_WGS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : 256); }();
+    for (uint32_t k0 = 0; k0 < pp.npk; k0 += batch) {
+        const uint32_t k1 = pp.npk - k0 < batch ? pp.npk : k0 + batch;
+        (void)hipMemsetAsync(work, 0, 2 * sizeof(uint32_t), st);
+        zz_l6m_params qm; qm.pk = pp; qm.m = m; qm.work = work + 1; qm.k0 = k0; qm.k1 = k1;
+        const dim3 gm((k1 - k0) < mgrid ? (k1 - k0) : mgrid), bm(ZZ_L6M_THREADS);   // one workgroup per CU: it takes the CU's LDS
+        if (xdepth == 2) hipLaunchKernelGGL((k_l6_matches<2>), gm, bm, 0, st, qm);
+        else if (xdepth == 4) hipLaunchKernelGGL((k_l6_matches<4>), gm, bm, 0, st, qm);
+        else hipLaunchKernelGGL((k_l6_matches<8>), gm, bm, 0, st, qm);
+        q.m = m; q.k0 = k0; q.k1 = k1;
+        const dim3 g(l2_grid(k1 - k0)), b(ZZ_L2_THREADS);
+        hipLaunchKernelGGL((k_encode_l2_t<32768u, true>), g, b, 0, st, q);
+    }
 }
 
 }  // namespace zz

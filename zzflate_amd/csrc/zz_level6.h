@@ -1,15 +1,15 @@
 // zz_level6.h -- the extended levels 4, 5, 6: bounded hash chains, one-step lazy matching, code lengths
 // by package-merge. NOT in the reference, which has one slot per hash, a greedy parse, a frequency-floor length limiter and
 // rejects level > 3 (encoder.h:41-43,76; encoder.cpp:388-424; huffman.cpp:122-154; zzflate.cpp:201,230-234); what this
-// file must be bit-exact with is the definition of these levels in the oracle, which it restates for a wavefront:
+// file must be bit-exact with is the definition of these levels in the oracle, which it restates for a GPU:
 //
 //   chains   every position q of the window in front of the packet and of the packet itself, up to target = n - 16, is
 //            entered under a 13-bit hash of its FOUR bytes, ascending; the candidates of q are the nearest DEPTH earlier
 //            positions with q's hash, as long as they are less than 32768 back. All positions are entered whatever the
 //            parse does, so the chains are parse-independent -- and stored FLATTENED: the positions sorted by (hash,
-//            position) in one array (a counting sort: histogram of the hashes in LDS, exclusive scan, then every block of
-//            64 positions takes consecutive places in its buckets, in lane order). The DEPTH entries in front of a
-//            position's own place are its chain, nearest last: one 2*DEPTH-byte load instead of DEPTH dependent hops.
+//            position) in one array (a counting sort: histogram of the hashes, exclusive scan, then every block of 64
+//            positions takes consecutive places in its buckets, in lane order). The DEPTH entries in front of a
+//            position's own place are its chain, nearest last: one 2*DEPTH-byte read instead of DEPTH dependent hops.
 //            Entries in front of a bucket's first belong to the bucket before (other four bytes: no match of four) or have
 //            not been written yet (the array is zeroed per packet: position -32768, out of reach): the chain ends there.
 //   match    16 bytes at q against 16 bytes at each candidate; the longest wins, the nearest among equals; >= 4 is a match;
@@ -18,17 +18,22 @@
 //            only when the parse reaches it -- the only thing here that depends on the parse;
 //   codes    optimal length-limited code lengths by package-merge in its list form (pm_lengths_w), wave-parallel: it replaces
 //            the heap replay of levels 2,3 (which exists only because ties must fall as libstdc++'s heap lets them fall).
-// The records, histograms, header and body emission are the level-2 ones (zz_level2.h), as is the two-wavefront split.
+//
+// Two kernels. Everything up to the parse is parse-independent and wants the whole sorted array (128 KiB of 16-bit entries,
+// 65,536 scattered two-byte stores per packet) in LDS, i.e. a CU to itself: k_l6_matches, one packet per 16-wavefront
+// workgroup, leaves per position "match length (lazy rule applied) and distance" in a 4-byte word. The parse, the records,
+// the histograms, the codes and the emission are sequential per packet and want MANY packets per CU: the level-2 kernel
+// (zz_level2.h), whose parser reads those words (l6_parse_pass) where levels 2,3 probe their table.
+// (Round 3's first form did all of it in the level-2 kernel with the array in global memory: 291 bytes of fabric traffic per
+// input byte, bound by that -- profiles/README.md.)
 #pragma once
 
 namespace zz {
 
-#define ZZ_L6_BIAS 32768u                          // array entries and table positions are position + 32768
+#define ZZ_L6_BIAS 32768u                          // array entries are position + 32768
 #define ZZ_L6_PAD 8u                               // entries in front of the sorted array (a chain read never starts below it)
 #define ZZ_L6_SORT_ENTRIES (65536u + 64u)
 #define ZZ_L6_SORT_BYTES (ZZ_L6_SORT_ENTRIES * 2u)  // positions sorted by (hash, position)
-#define ZZ_L6_IDX_BYTES (32768u * 2u)               // place of every packet position in that array
-#define ZZ_L6_SCRATCH_BYTES (ZZ_L6_SORT_BYTES + ZZ_L6_IDX_BYTES)
 #define ZZ_L6_TAIL 16u                              // target = n - 16: the 16 bytes compared at a position lie inside the data
 #define ZZ_L6_CAP 16u
 
@@ -36,185 +41,247 @@ __device__ __forceinline__ uint32_t l6_hash4(uint32_t four_bytes) { return (four
 __device__ __forceinline__ uint32_t l6_target(uint32_t n) { return n > ZZ_L6_TAIL ? n - ZZ_L6_TAIL : 0u; }
 __device__ __forceinline__ uint32_t l6_trips(uint32_t n) { return (l6_target(n) + 63u) >> 6; }
 
-// ---- the helper wavefront's share of the preparation: the sorted array starts out as zeros --------------------------------
-__device__ __forceinline__ void l6_zero_sorted(uint16_t* sorted, uint32_t entries)
-{
-    uint4* z = (uint4*)sorted;
-    const uint32_t n16 = (entries * 2u + 15u) >> 4;
-    for (uint32_t i = (uint32_t)lane_id(); i < n16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // written before the other wavefront's stores to the same lines are issued
-}
+// ===== kernel 1: per position, the best match of its chain ====================================================================
+// One packet per workgroup of 16 wavefronts, 160 KiB of LDS: the sorted array (131,200 bytes), 8192 16-bit bucket counters
+// (16 KiB), and a ring of hand-over slots (15 KiB). Per packet:
+//   1  all: array and counters to zero; histogram of the hashes of positions -W .. target-1 (LDS atomics on the packed
+//      counters); exclusive scan -> every bucket's first place;
+//   2  rounds of 30 blocks of 64 positions, ascending, one workgroup barrier per round, three rounds in flight:
+//      - the 15 WORKER wavefronts prepare round t: per block, every position's hash and its rank among the positions of the
+//        block with the same hash (13 ballots), the size of that set with its first lane -> ring slot;
+//      - wavefront 0, the PLACER, takes round t-1 from the ring: place = counter[hash] + rank, the first lane of a set moves
+//        the counter on by the set's size, sorted[place] = position; the place goes back into the ring slot. Its chain per
+//        block is one LDS round trip -- the serial part of the counting sort, the only part that is;
+//      - the workers take the places of round t-2 from the ring and, for the packet's own positions, read the chain (all
+//        earlier positions stand in the array by now; later ones land behind them or in other buckets), fetch the
+//        candidates' bytes (the window and the packet: 64 KiB per resident packet, 16 MiB on the chip -- they stay in the
+//        L2s), pick the best, apply the lazy rule inside the block and store one word per position.
+// m[q] = length << 16 | distance for a position that starts a match if the parse reaches it, 0 otherwise.
+#define ZZ_L6M_THREADS 1024u
+#define ZZ_L6M_ROUND 30u                            // blocks per round: two per worker wavefront
+struct zz_l6m_params {
+    zz_packet_params pk;
+    uint32_t* m;            // one word per input byte of the packets k0 .. k1-1
+    uint32_t* work;         // packets handed out beyond the first gridDim.x (zero at launch)
+    uint32_t k0, k1;
+};
 
-// ---- counting sort, part 1: how many positions per hash, then where each bucket starts ------------------------------------
-// T: 8192 16-bit counters (the level-2 hash table's space), zero on entry; on exit T[h] = the place of the next position with
-// hash h. Positions -W .. target-1 (W + target < 65536: the counts, and the places, fit 16 bits).
-__device__ __forceinline__ void l6_histogram_and_scan(uint16_t* T, const uint8_t* src, int32_t W, uint32_t target)
+template <int DEPTH>
+__device__ __forceinline__ void l6m_match_block(const uint16_t* sorted, const uint8_t* src, const uint8_t* end, uint32_t target,
+                                                uint32_t b, uint32_t place, uint32_t* mrow)
 {
     const int lane = lane_id();
-    uint32_t* Tw = (uint32_t*)T;
-    const int32_t lo = -W, hi = (int32_t)target;
-    for (int32_t g = lo; g < hi; g += 8 * ZZ_WAVE) {          // eight loads in flight per trip
-        uint32_t v[8];
+    const uint32_t q = (b << 6) + (uint32_t)lane;
+    const bool act = q < target;
+    const uint32_t qa = act ? q : 0u;
+    uint16_t c[DEPTH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int32_t pos = g + u * ZZ_WAVE + lane;
-            v[u] = load32(src + (pos < hi ? pos : lo));
-        }
+    for (int k = 0; k < DEPTH; ++k) c[k] = sorted[ZZ_L6_PAD + place - DEPTH + k];     // nearest last
+    uint64_t w, w2, cw[DEPTH], cw2[DEPTH];
+    uint32_t dist[DEPTH];
+    ld128<false>(src + qa, end, w, w2);                                     // q + 16 <= n: inside the data
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int32_t pos = g + u * ZZ_WAVE + lane;
-            const uint32_t h = l6_hash4(v[u]);
-            if (pos < hi) atomicAdd(&Tw[h >> 1], 1u << ((h & 1u) << 4));
-        }
+    for (int k = 0; k < DEPTH; ++k) {                                       // k = 0: the nearest
+        const int32_t cp = (int32_t)c[DEPTH - 1 - k] - (int32_t)ZZ_L6_BIAS;
+        const uint32_t d = q - (uint32_t)cp;                                // 0 < d < 32768: a candidate
+        const bool ok = act && (d - 1u) < 32767u;
+        dist[k] = ok ? d : 0u;
+        ld128<false>(src + (ok ? cp : (int32_t)qa), end, cw[k], cw2[k]);
     }
-    ZZ_WAVE_SYNC();
-    // exclusive scan over the 8192 counters: a lane owns 128 consecutive ones (64 words)
-    uint32_t* mine = Tw + 64 * lane;
-    uint32_t s = 0;
-    for (int i = 0; i < 64; i += 4) {
-        const uint4 w = *(const uint4*)(mine + i);
-        s += (w.x & 0xFFFF) + (w.x >> 16) + (w.y & 0xFFFF) + (w.y >> 16) + (w.z & 0xFFFF) + (w.z >> 16) + (w.w & 0xFFFF) + (w.w >> 16);
+    uint32_t best = 0, bdist = 0;
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+        uint32_t len = equal_bits128(w ^ cw[k], w2 ^ cw2[k], 128u) >> 3;
+        if (!dist[k]) len = 0;
+        if (len > best) { best = len; bdist = dist[k]; }
     }
-    uint32_t r = wave_scan_incl(s) - s;
-    for (int i = 0; i < 64; ++i) {
-        const uint32_t w = mine[i];
-        const uint32_t a = r, b = r + (w & 0xFFFF);
-        r = b + (w >> 16);
-        mine[i] = (a & 0xFFFF) | (b << 16);
-    }
-    ZZ_WAVE_SYNC();
+    if (best < 4) best = 0;
+    // lazy: the next position's length (lane 63 never defers)
+    const uint32_t nxt = (uint32_t)__shfl_down((int)best, 1);
+    const bool defer = best != 0 && best < ZZ_L6_CAP && lane != 63 && nxt > best;
+    if (act) mrow[q] = (best != 0 && !defer) ? (best << 16) | bdist : 0u;
 }
 
-// ---- counting sort, part 2: every position takes its place ----------------------------------------------------------------
-// Blocks of 64 positions, ascending; the positions of a block that share a hash take consecutive places in lane order (the
-// read-back of a lane tag written to the bucket's counter names one lane per set of equal hashes: six ballots give every lane
-// its set, zz_wave.h). The parsing wavefront only works the counters: the places of a block go to the helper wavefront
-// through an LDS slot (two slots, one s_barrier per block), and the helper does the stores -- sorted[PAD + place] = position +
-// BIAS, idx[q] = place for the packet's own positions. (With the stores on the parser's own memory queue, every wait for its
-// next positions' bytes was a wait for all the scattered two-byte stores before them: 27 % of a level-6 packet.)
-__device__ __forceinline__ uint32_t l6_place_blocks(int32_t W, uint32_t target)
+template <int DEPTH>
+__global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
 {
-    return ((((uint32_t)W + 63u) & ~63u) + ((target + 63u) & ~63u)) >> 6;
-}
-__device__ __forceinline__ void l6_place_all(uint16_t* T, uint32_t spare, uint32_t* hb, const uint8_t* src, int32_t W, uint32_t target)
-{
+    const zz_packet_params& P = Q.pk;
+    __shared__ __attribute__((aligned(16))) uint16_t sorted[ZZ_L6_SORT_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint32_t Tw[ZZ_HASH_SIZE / 2 + 4];      // 8192 16-bit counters, two per word (+ the one lanes without a position use)
+    __shared__ __attribute__((aligned(16))) uint32_t ring[2][ZZ_L6M_ROUND][ZZ_WAVE];
+    __shared__ uint32_t wtot[ZZ_L6M_THREADS / ZZ_WAVE];
+    __shared__ uint32_t nextk;
+    uint16_t* const T = (uint16_t*)Tw;
+    const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
+    const uint32_t wave = uniform(tid >> 6);
     const uint64_t below_me = (1ull << lane) - 1;
-    const int32_t lo = -W, hi = (int32_t)target;
-    uint32_t slotsel = 0;
-    // (blocks are aligned to the packet: the first window block may be partial; four blocks' bytes are requested per trip)
-    for (int32_t g0 = -(int32_t)(((uint32_t)W + 63u) & ~63u); g0 < hi; g0 += 4 * ZZ_WAVE) {
-        uint32_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int32_t pos = g0 + u * ZZ_WAVE + lane;
-            v[u] = load32(src + ((pos >= lo && pos < hi) ? pos : lo));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int32_t g = g0 + u * ZZ_WAVE;
-            if (g >= hi) break;                                             // (uniform)
-            const int32_t pos = g + lane;
-            const bool act = pos >= lo && pos < hi;
-            const uint32_t h = act ? l6_hash4(v[u]) : spare;                // lanes without a position share a spare counter
-            const uint32_t old = T[h];
-            T[h] = (uint16_t)lane;
-            ZZ_WAVE_SYNC();
-            const uint32_t rb = T[h];
-            ZZ_WAVE_SYNC();
-            uint32_t place = old, cnt = 1;
-            if (ballot(rb != (uint32_t)lane)) {
-                const uint64_t set = wave_match6(rb);
-                place = old + (uint32_t)__builtin_popcountll(set & below_me);
-                cnt = (uint32_t)__builtin_popcountll(set);
+    ZZ_PROF_DECL
+
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);        // the placer's chain is the serial part of a packet
+    uint32_t k = Q.k0 + blockIdx.x;
+    while (k < Q.k1) {
+        const uint64_t off = (uint64_t)k * P.packet_size;
+        const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
+        const bool is_final = P.last_is_final && k == P.npk - 1;
+        const uint32_t n = is_final ? len : len - 1;      // bytes of the compressing AddData (zz_level2.h)
+        const uint8_t* src = P.src + off;
+        const uint8_t* end = P.src + P.n;
+        const uint64_t before = P.halo + off;
+        const int32_t W = (int32_t)(before < P.warm ? before : P.warm);
+        const uint32_t target = l6_target(n);
+        uint32_t* const mrow = Q.m + (uint64_t)(k - Q.k0) * P.packet_size;
+        if (target) {
+            const int32_t lo = -W, hi = (int32_t)target;
+            ZZ_T(13);
+            // ---- 1: zero, histogram, scan ----
+            {
+                uint4* z = (uint4*)sorted;
+                const uint32_t n16 = ((ZZ_L6_PAD + (uint32_t)W + target) * 2u + 15u) >> 4;
+                for (uint32_t i = tid; i < n16; i += ZZ_L6M_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+                ((uint4*)Tw)[tid] = make_uint4(0, 0, 0, 0);
             }
-            if (rb == (uint32_t)lane) T[h] = (uint16_t)(old + cnt);          // one lane per set moves the counter on
-            (hb + slotsel)[lane] = place;
-            slotsel ^= ZZ_L2_HB_WORDS;
-            l2_block_barrier();
+            __syncthreads();
+            ZZ_T(6);
+            for (int32_t p0 = lo + (int32_t)tid; p0 < hi; p0 += 4 * (int32_t)ZZ_L6M_THREADS) {      // four loads in flight
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t pos = p0 + u * (int32_t)ZZ_L6M_THREADS;
+                    v[u] = load32(src + (pos < hi ? pos : lo));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t pos = p0 + u * (int32_t)ZZ_L6M_THREADS;
+                    const uint32_t h = l6_hash4(v[u]);
+                    if (pos < hi) atomicAdd(&Tw[h >> 1], 1u << ((h & 1u) << 4));
+                }
+            }
+            __syncthreads();
+            ZZ_T(7);
+            {   // exclusive scan over the 8192 counters: a thread owns eight consecutive ones (W + target < 65536: places fit 16 bits)
+                uint4 w = ((uint4*)Tw)[tid];
+                const uint32_t c0 = w.x & 0xFFFF, c1 = w.x >> 16, c2 = w.y & 0xFFFF, c3 = w.y >> 16;
+                const uint32_t c4 = w.z & 0xFFFF, c5 = w.z >> 16, c6 = w.w & 0xFFFF, c7 = w.w >> 16;
+                const uint32_t s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+                const uint32_t incl = wave_scan_incl(s);
+                if (lane == 63) wtot[wave] = incl;
+                __syncthreads();
+                uint32_t e = incl - s;
+                for (uint32_t i = 0; i < wave; ++i) e += wtot[i];
+                const uint32_t a1 = e + c0, a2 = a1 + c1, a3 = a2 + c2, a4 = a3 + c3, a5 = a4 + c4, a6 = a5 + c5, a7 = a6 + c6;
+                w.x = (e & 0xFFFF) | (a1 << 16); w.y = (a2 & 0xFFFF) | (a3 << 16);
+                w.z = (a4 & 0xFFFF) | (a5 << 16); w.w = (a6 & 0xFFFF) | (a7 << 16);
+                ((uint4*)Tw)[tid] = w;
+            }
+            __syncthreads();
+            ZZ_T(8);
+            // ---- 2: the rounds ----
+            // (blocks are aligned to the packet: the first window block may be partial; blocks below 0 hold window positions only)
+            const uint32_t Wr = ((uint32_t)W + 63u) & ~63u;
+            const int32_t g0 = -(int32_t)Wr;
+            const uint32_t nblk = (Wr + ((target + 63u) & ~63u)) >> 6;
+            const uint32_t NR = (nblk + ZZ_L6M_ROUND - 1u) / ZZ_L6M_ROUND;
+            uint32_t vnext[2];                         // workers: the four bytes at their positions of the next round
+            auto fetch = [&](uint32_t t) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t bi = t * ZZ_L6M_ROUND + 2u * (wave - 1u) + (uint32_t)u;
+                    const int32_t pos = g0 + (int32_t)(bi << 6) + lane;
+                    vnext[u] = load32(src + ((bi < nblk && pos >= lo && pos < hi) ? pos : lo));
+                }
+            };
+            if (wave != 0) fetch(0);
+            for (uint32_t t = 0; t <= NR + 1; ++t) {
+                if (wave == 0) {
+                    if (t >= 1 && t <= NR) {
+                        // The placer. The LDS serves the lanes of one instruction that add to one address in ascending lane
+                        // order, and a wavefront's LDS instructions in issue order (tools/ubench_lds_atomic_order.hip, and the
+                        // library's own zz_debug_lds_atomic_order behind a GPU test): ds_add_rtn on the bucket's counter IS the
+                        // place of every position, block after block -- no ranking of equal hashes, no wait between blocks.
+                        const uint32_t r0 = (t - 1) * ZZ_L6M_ROUND;
+                        const uint32_t cnt = nblk - r0 < ZZ_L6M_ROUND ? nblk - r0 : ZZ_L6M_ROUND;
+                        uint32_t* const slots = &ring[(t - 1) & 1][0][0];
+                        const uint32_t val0 = (uint32_t)(g0 + (int32_t)(r0 << 6) + lane + (int32_t)ZZ_L6_BIAS);
+                        uint32_t inf[ZZ_L6M_ROUND], old[ZZ_L6M_ROUND];
+#pragma unroll
+                        for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) inf[s] = slots[s * ZZ_WAVE + (uint32_t)lane];
+#pragma unroll
+                        for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s)
+                            if (s < cnt) old[s] = atomicAdd((uint32_t*)((uint8_t*)Tw + (inf[s] & 0xFFFFu)), 1u << (inf[s] >> 16));
+                        ZZ_T(15);
+#pragma unroll
+                        for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) {
+                            if (s < cnt) {
+                                const uint32_t place = __builtin_amdgcn_ubfe(old[s], inf[s] >> 16, 16);
+                                if ((int32_t)inf[s] >= 0) {                        // (a lane without a position added to a counter of its own)
+                                    sorted[ZZ_L6_PAD + place] = (uint16_t)(val0 + (s << 6));
+                                    slots[s * ZZ_WAVE + (uint32_t)lane] = place;
+                                }
+                            }
+                        }
+                    }
+                    ZZ_T(14);
+                } else {
+                    const uint32_t s0 = 2u * (wave - 1u);
+                    uint32_t place[2] = { 0, 0 };
+                    uint32_t mb[2] = { ~0u, ~0u };              // the packet block to match (round t-2), ~0: none
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t bi = (t - 2) * ZZ_L6M_ROUND + s0 + (uint32_t)u;
+                        if (t >= 2 && bi < nblk && bi >= (Wr >> 6)) { mb[u] = bi - (Wr >> 6); place[u] = ring[t & 1][s0 + u][lane]; }
+                    }
+                    ZZ_WAVE_SYNC();
+                    if (t < NR) {
+                        // the next round's hashes, as the placer wants them: byte address of the counter's word | shift << 16
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t bi = t * ZZ_L6M_ROUND + s0 + (uint32_t)u;
+                            const int32_t pos = g0 + (int32_t)(bi << 6) + lane;
+                            const bool act = bi < nblk && pos >= lo && pos < hi;
+                            const uint32_t h = l6_hash4(vnext[u]);
+                            ring[t & 1][s0 + u][lane] = act ? (((h >> 1) << 2) | ((h & 1u) << 20)) : (0x80000000u | (ZZ_HASH_SIZE * 2u));
+                        }
+                        fetch(t + 1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (mb[u] != ~0u) l6m_match_block<DEPTH>(sorted, src, end, target, mb[u], place[u], mrow);
+                }
+                __syncthreads();
+                if (t * ZZ_L6M_ROUND < (Wr >> 6) + 2 * ZZ_L6M_ROUND) { ZZ_T(9); } else { ZZ_T(12); }   // rounds without / with matching
+            }
         }
+        __syncthreads();
+        if (tid == 0) nextk = Q.k0 + gridDim.x + atomicAdd(Q.work, 1u);
+        __syncthreads();
+        k = nextk;
     }
-}
-// the helper's side: one barrier per block, then the block's stores
-__device__ __forceinline__ void l6_store_places(const uint32_t* hb, int32_t W, uint32_t target, uint16_t* sorted, uint16_t* idx)
-{
-    const int lane = lane_id();
-    const int32_t lo = -W, hi = (int32_t)target;
-    uint32_t slotsel = 0;
-    for (int32_t g = -(int32_t)(((uint32_t)W + 63u) & ~63u); g < hi; g += ZZ_WAVE) {
-        l2_block_barrier();
-        const uint32_t place = (hb + slotsel)[lane];
-        slotsel ^= ZZ_L2_HB_WORDS;
-        const int32_t pos = g + lane;
-        if (pos >= lo && pos < hi) {
-            sorted[ZZ_L6_PAD + place] = (uint16_t)(pos + (int32_t)ZZ_L6_BIAS);
-            if (pos >= 0) idx[pos] = (uint16_t)place;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // in memory before the other wavefront reads them
+    ZZ_PROF_FLUSH(P);
 }
 
-// ---- the token pass: best of the chain, lazy evaluation, greedy parse; hands every block's matches to the helper wavefront
-// in the level-2 format (zz_level2.h: ZZ_L2_HB_PACK, one s_barrier per block). ---------------------------------------------
-// Everything up to the parse is parse-independent, so the loads run ahead of their use as a three-stage pipeline: while
-// block b-1 is compared and parsed, the candidates' bytes of block b, the chain of block b+1 and the place of block b+2 are
-// in flight (a block's loads depend on each other: place -> chain -> bytes, three trips to the L2 that would otherwise stand
-// in front of every block).
-template <int DEPTH, bool SAFE>
-__device__ __forceinline__ void l6_match_pass(uint32_t* hb, const uint8_t* src, const uint8_t* end, uint32_t n,
-                                              const uint16_t* sorted, const uint16_t* idx)
+// ===== kernel 2's parser: the greedy parse over those words; hands every block's matches to the helper wavefront in the
+// level-2 format (zz_level2.h: ZZ_L2_HB_PACK, one s_barrier per block) =========================================================
+template <bool SAFE>
+__device__ __forceinline__ void l6_parse_pass(uint32_t* hb, const uint8_t* src, const uint8_t* end, uint32_t n, const uint32_t* mrow)
 {
     const int lane = lane_id();
     const uint32_t target = l6_target(n);
     const uint32_t nblk = (target + 63u) >> 6;
     uint32_t nextpos = 0;                   // first position the parse has not decided
     uint32_t slotsel = 0;
-    struct chain_t { uint16_t c[DEPTH]; };
-    struct bytes_t { uint64_t w, w2, cw[DEPTH], cw2[DEPTH]; uint32_t dist[DEPTH]; };
-    // stage A: where block b's positions stand in the sorted array
-    auto stageA = [&](uint32_t b) -> uint32_t {
+    auto ldm = [&](uint32_t b) -> uint32_t {
         const uint32_t q = (b << 6) + (uint32_t)lane;
-        return idx[q < target ? q : 0u];                                    // (lanes past the target: any valid place)
+        return (b < nblk && q < target) ? mrow[q] : 0u;
     };
-    // stage B: the chain -- the DEPTH entries in front of the position's place, nearest last
-    auto stageB = [&](uint32_t place) -> chain_t {
-        chain_t ch;
-        __builtin_memcpy(ch.c, sorted + ZZ_L6_PAD + place - DEPTH, 2 * DEPTH);
-        return ch;
-    };
-    // stage C: 16 bytes at the position and at every candidate
-    auto stageC = [&](uint32_t b, const chain_t& ch) -> bytes_t {
-        bytes_t y;
-        const uint32_t q = (b << 6) + (uint32_t)lane;
-        const bool act = q < target;
-        const uint32_t qa = act ? q : 0u;
-        ld128<false>(src + qa, end, y.w, y.w2);                             // q + 16 <= n: inside the data
-#pragma unroll
-        for (int k = 0; k < DEPTH; ++k) {                                   // k = 0: the nearest
-            const int32_t c = (int32_t)ch.c[DEPTH - 1 - k] - (int32_t)ZZ_L6_BIAS;
-            const uint32_t d = q - (uint32_t)c;                             // 0 < d < 32768: a candidate
-            const bool ok = act && (d - 1u) < 32767u;
-            y.dist[k] = ok ? d : 0u;
-            ld128<false>(src + (ok ? c : (int32_t)qa), end, y.cw[k], y.cw2[k]);
-        }
-        return y;
-    };
-    // stage D: best of the chain, lazy evaluation, the parse, hand-over
-    auto stageD = [&](uint32_t b, const bytes_t& y) {
+    if (nblk == 0) return;
+    uint32_t m0 = ldm(0), m1 = ldm(1), m2 = ldm(2);        // three blocks' words in flight
+    for (uint32_t b = 0; b < nblk; ++b) {
+        const uint32_t mN = ldm(b + 3);
         const uint32_t base = b << 6;
         const uint32_t q = base + (uint32_t)lane;
-        uint32_t best = 0, bdist = 0;
-#pragma unroll
-        for (int k = 0; k < DEPTH; ++k) {
-            uint32_t len = equal_bits128(y.w ^ y.cw[k], y.w2 ^ y.cw2[k], 128u) >> 3;
-            if (!y.dist[k]) len = 0;
-            if (len > best) { best = len; bdist = y.dist[k]; }
-        }
-        if (best < 4) best = 0;
-        // lazy: the next position's length (lane 63 never defers)
-        const uint32_t nxt = (uint32_t)__shfl_down((int)best, 1);
-        const bool defer = best != 0 && best < ZZ_L6_CAP && lane != 63 && nxt > best;
-        const uint64_t E = ballot(best != 0 && !defer);
+        const uint32_t best = m0 >> 16, bdist = m0 & 0xFFFFu;
+        const uint64_t E = ballot(best != 0);
         // the parse: from match to match
         uint64_t evmask = 0;
         uint32_t tlen = best;               // per lane: the match's length (extended where the parse reached a capped one)
@@ -242,25 +309,7 @@ __device__ __forceinline__ void l6_match_pass(uint32_t* hb, const uint8_t* src, 
         slot[66] = (uint32_t)evmask; slot[67] = (uint32_t)(evmask >> 32);     // all of them carry start, length, distance
         slot[68] = 0;
         l2_block_barrier();
-    };
-    if (nblk == 0) return;
-    // prologue: fill the pipeline
-    uint32_t placeA = stageA(0);
-    chain_t chB = stageB(placeA);
-    placeA = stageA(nblk > 1 ? 1u : 0u);
-    bytes_t yC = stageC(0, chB);
-    chB = stageB(placeA);
-    placeA = stageA(nblk > 2 ? 2u : 0u);
-    for (uint32_t b = 0; b < nblk; ++b) {
-        // requests for the blocks behind this one go out first ...
-        bytes_t yN;
-        const bool more = b + 1 < nblk;
-        if (more) yN = stageC(b + 1, chB);
-        chB = stageB(placeA);
-        placeA = stageA(b + 3 < nblk ? b + 3 : 0u);
-        // ... then this block is worked on while they travel
-        stageD(b, yC);
-        if (more) yC = yN;
+        m0 = m1; m1 = m2; m2 = mN;
     }
 }
 

@@ -89,6 +89,21 @@ __device__ __forceinline__ uint64_t wave_match6(uint32_t key)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The same for keys of NB bits (the 13-bit hashes of the extended levels' counting sort): one ballot per bit. Left to the
+// compiler's scheduling -- its callers are not on a packet's critical path.
+template <int NB> __device__ __forceinline__ uint64_t wave_match_bits(uint32_t key)
+{
+    uint32_t lo = ~0u, hi = ~0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t m = (uint32_t)((int32_t)(key << (31 - b)) >> 31);      // my bit b as a mask
+        const uint64_t B = ballot(m != 0);
+        lo = __builtin_amdgcn_bitop3_b32((uint32_t)B, m, lo, 0x82);            // ~(ballot ^ mybit) & set
+        hi = __builtin_amdgcn_bitop3_b32((uint32_t)(B >> 32), m, hi, 0x82);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // A 64-bit scalar mask used directly as the lane predicate of a select (lane l takes `a` where bit l is set): one
 // v_cndmask, where the compiler would shift the mask by the lane id and test a bit (three or four instructions).
 // `m` must have been written by SCALAR instructions (inline-asm "=s" outputs, or uniform integer arithmetic): an SGPR
