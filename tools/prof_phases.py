@@ -44,8 +44,8 @@ if level >= 2:
         print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
     pk = max(1, prof[10])
     if level >= 4:
-        print("  k_l6_matches (cycles/packet, wavefront 0): zero %.0f | histogram %.0f | scan %.0f | rounds before the packet's own blocks %.0f | rounds with matching %.0f | between packets %.0f; of the rounds, the placer's own work %.0f (+ %.0f up to its last add's issue)" % (
-            prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[13] / pk, prof[14] / pk, prof[15] / pk))
+        print("  k_l6_matches (cycles/packet, wavefront 0): zero %.0f | histogram %.0f | scan %.0f | rounds before the packet's own blocks %.0f | rounds with chain copies %.0f | window and packet into LDS %.0f | compares %.0f | between packets %.0f" % (
+            prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[15] / pk, prof[14] / pk, prof[13] / pk))
         sys.exit(0)
     print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f | finish block %.0f" % (
         prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[13] / pk))

@@ -44,9 +44,24 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, uint32_t seed
                 for (int s = 0; s < 30; ++s) o[s] = ring[r & 1][s][lane];
 #pragma unroll
                 for (int s = 0; s < 30; ++s) sink += o[s];
-            } else {
+            } else if (KIND == 5) {
 #pragma unroll
                 for (int s = 0; s < 30; ++s) o[s] = ((uint16_t*)Tw)[a[s]];
+#pragma unroll
+                for (int s = 0; s < 30; ++s) sink += o[s];
+            } else if (KIND == 6) {            // two adjacent 8-byte words at a random 8-aligned offset of a 64 KiB image (ds_read2_b64)
+#pragma unroll
+                for (int s = 0; s < 30; ++s) { const uint64_t* p = (const uint64_t*)((const uint8_t*)sorted + a[s] * 8); const uint64_t u = p[0], v = p[1]; o[s] = (uint32_t)(u ^ (v >> 7)); }
+#pragma unroll
+                for (int s = 0; s < 30; ++s) sink += o[s];
+            } else if (KIND == 7) {            // one 8-byte word at a random 8-aligned offset
+#pragma unroll
+                for (int s = 0; s < 30; ++s) { const uint64_t* p = (const uint64_t*)((const uint8_t*)sorted + a[s] * 8); const uint64_t u = p[0]; o[s] = (uint32_t)(u ^ (u >> 37)); }
+#pragma unroll
+                for (int s = 0; s < 30; ++s) sink += o[s];
+            } else {                           // one 4-byte word at a random 4-aligned offset
+#pragma unroll
+                for (int s = 0; s < 30; ++s) o[s] = ((const uint32_t*)sorted)[a[s] * 2 + (lane & 1)];
 #pragma unroll
                 for (int s = 0; s < 30; ++s) sink += o[s];
             }
@@ -79,5 +94,6 @@ int main()
     run<3, false>("ds_write_b32 lane-contiguous"); run<3, true>("ds_write_b32 lane-contiguous");
     run<4, false>("ds_read_b32 lane-contiguous"); run<4, true>("ds_read_b32 lane-contiguous");
     run<5, false>("ds_read_u16 scattered"); run<5, true>("ds_read_u16 scattered");
+    run<6, false>("ds_read2_b64 scattered, 8-aligned"); run<7, false>("ds_read_b64 scattered, 8-aligned"); run<8, false>("ds_read_b32 scattered");
     return 0;
 }

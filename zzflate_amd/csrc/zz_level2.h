@@ -1331,10 +1331,16 @@ static inline uint32_t l6_batch_packets(uint32_t npk, uint32_t P)
     const uint64_t b = bytes / P ? bytes / P : 1;
     return (uint32_t)(b < npk ? b : npk);
 }
+static inline uint32_t l6_match_grid()      // one workgroup per CU: it takes the CU's LDS
+{
+    static const uint32_t g = [] { const char* e = getenv("ZZFLATE_L6_MATCH_WGS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 1024 ? v : 256); }();
+    return g;
+}
+static inline uint64_t l6_m_bytes(uint32_t npk, uint32_t P) { return ((uint64_t)l6_batch_packets(npk, P) * P * 4u + 255u) & ~255ull; }
 static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth, uint32_t P)
 {
     uint64_t need = (uint64_t)l2_grid(npk) * ZZ_L2_SCRATCH_BYTES;
-    if (xdepth) need += (uint64_t)l6_batch_packets(npk, P) * P * 4u;
+    if (xdepth) need += l6_m_bytes(npk, P) + (uint64_t)l6_match_grid() * 32768u * 2u * (uint32_t)xdepth;   // + the chains of every resident packet
     return need;
 }
 static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st, int xdepth = 0)
@@ -1349,12 +1355,13 @@ static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, u
     }
     uint32_t* const m = (uint32_t*)(scratch + (uint64_t)l2_grid(pp.npk) * ZZ_L2_SCRATCH_BYTES);
     const uint32_t batch = l6_batch_packets(pp.npk, pp.packet_size);
-    static const uint32_t mgrid = [] { const char* e = getenv("ZZFLATE_L6_MATCH_WGS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : 256); }();
+    const uint32_t mgrid = l6_match_grid();
+    uint16_t* const chains = (uint16_t*)((uint8_t*)m + l6_m_bytes(pp.npk, pp.packet_size));
     for (uint32_t k0 = 0; k0 < pp.npk; k0 += batch) {
         const uint32_t k1 = pp.npk - k0 < batch ? pp.npk : k0 + batch;
         (void)hipMemsetAsync(work, 0, 2 * sizeof(uint32_t), st);
-        zz_l6m_params qm; qm.pk = pp; qm.m = m; qm.work = work + 1; qm.k0 = k0; qm.k1 = k1;
-        const dim3 gm((k1 - k0) < mgrid ? (k1 - k0) : mgrid), bm(ZZ_L6M_THREADS);   // one workgroup per CU: it takes the CU's LDS
+        zz_l6m_params qm; qm.pk = pp; qm.m = m; qm.chains = chains; qm.work = work + 1; qm.k0 = k0; qm.k1 = k1;
+        const dim3 gm((k1 - k0) < mgrid ? (k1 - k0) : mgrid), bm(ZZ_L6M_THREADS);
         if (xdepth == 2) hipLaunchKernelGGL((k_l6_matches<2>), gm, bm, 0, st, qm);
         else if (xdepth == 4) hipLaunchKernelGGL((k_l6_matches<4>), gm, bm, 0, st, qm);
         else hipLaunchKernelGGL((k_l6_matches<8>), gm, bm, 0, st, qm);

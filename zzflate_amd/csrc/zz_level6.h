@@ -20,8 +20,9 @@
 //            the heap replay of levels 2,3 (which exists only because ties must fall as libstdc++'s heap lets them fall).
 //
 // Two kernels. Everything up to the parse is parse-independent and wants the whole sorted array (128 KiB of 16-bit entries,
-// 65,536 scattered two-byte stores per packet) in LDS, i.e. a CU to itself: k_l6_matches, one packet per 16-wavefront
-// workgroup, leaves per position "match length (lazy rule applied) and distance" in a 4-byte word. The parse, the records,
+// 65,536 scattered two-byte stores per packet) in LDS and then the 64 KiB of window and packet for the compares, i.e. a CU to
+// itself: k_l6_matches, one packet per 16-wavefront workgroup, leaves per position "match length (lazy rule applied) and
+// distance" in a 4-byte word. The parse, the records,
 // the histograms, the codes and the emission are sequential per packet and want MANY packets per CU: the level-2 kernel
 // (zz_level2.h), whose parser reads those words (l6_parse_pass) where levels 2,3 probe their table.
 // (Round 3's first form did all of it in the level-2 kernel with the array in global memory: 291 bytes of fabric traffic per
@@ -42,83 +43,91 @@ __device__ __forceinline__ uint32_t l6_target(uint32_t n) { return n > ZZ_L6_TAI
 __device__ __forceinline__ uint32_t l6_trips(uint32_t n) { return (l6_target(n) + 63u) >> 6; }
 
 // ===== kernel 1: per position, the best match of its chain ====================================================================
-// One packet per workgroup of 16 wavefronts, 160 KiB of LDS: the sorted array (131,200 bytes), 8192 16-bit bucket counters
-// (16 KiB), and a ring of hand-over slots (15 KiB). Per packet:
-//   1  all: array and counters to zero; histogram of the hashes of positions -W .. target-1 (LDS atomics on the packed
+// One packet per workgroup of 16 wavefronts, 160 KiB of LDS. Per packet:
+//   1  all: array and counters to zero; histogram of the hashes of positions -W .. target-1 (LDS atomics on the packed 16-bit
 //      counters); exclusive scan -> every bucket's first place;
-//   2  rounds of 30 blocks of 64 positions, ascending, one workgroup barrier per round, three rounds in flight:
-//      - the 15 WORKER wavefronts prepare round t: per block, every position's hash and its rank among the positions of the
-//        block with the same hash (13 ballots), the size of that set with its first lane -> ring slot;
-//      - wavefront 0, the PLACER, takes round t-1 from the ring: place = counter[hash] + rank, the first lane of a set moves
-//        the counter on by the set's size, sorted[place] = position; the place goes back into the ring slot. Its chain per
-//        block is one LDS round trip -- the serial part of the counting sort, the only part that is;
-//      - the workers take the places of round t-2 from the ring and, for the packet's own positions, read the chain (all
-//        earlier positions stand in the array by now; later ones land behind them or in other buckets), fetch the
-//        candidates' bytes (the window and the packet: 64 KiB per resident packet, 16 MiB on the chip -- they stay in the
-//        L2s), pick the best, apply the lazy rule inside the block and store one word per position.
+//   2  the sort, in rounds of 30 blocks of 64 positions, ascending, one workgroup barrier per round, three rounds in flight:
+//      - the 15 WORKER wavefronts prepare round t: the hashes of their two blocks, as the counter's address and shift -> ring;
+//      - wavefront 0, the PLACER, takes round t-1 from the ring: one returning add per block on the buckets' counters. The LDS
+//        serves the lanes of one instruction that add to one address in ascending lane order, and one wavefront's instructions
+//        in issue order (tools/ubench_lds_atomic_order.hip; zz_debug_lds_atomic_order behind a GPU test), so what the add
+//        returns IS the position's place: no ranking of equal hashes, no wait between blocks. sorted[place] = position; the
+//        place goes back into the ring slot;
+//      - the workers take the places of round t-2 from the ring and, for the packet's own positions, copy the chain -- the
+//        DEPTH entries in front of the place; all earlier positions stand in the array by now, later ones land behind them
+//        or in other buckets -- to the workgroup's scratch in global memory (2*DEPTH bytes per position, coalesced);
+//   3  the array is dead: the window and the packet (<= 64 KiB) take its place in LDS, and all 16 wavefronts compare -- per
+//      position 16 bytes against 16 bytes at each candidate, gathered from LDS (three 8-byte reads and a funnel shift each; from
+//      global memory every candidate was a 128-byte line for 16 bytes of it, and the load path, not the CU, set the pace);
+//      best of the chain, the lazy rule inside the block, one word per position.
 // m[q] = length << 16 | distance for a position that starts a match if the parse reaches it, 0 otherwise.
 #define ZZ_L6M_THREADS 1024u
+#define ZZ_L6M_PLACERS 1u                           // wavefront 0 (two, each with the buckets of one parity, were slower: 34.6 against 30.7 ms at level 6)
 #define ZZ_L6M_ROUND 30u                            // blocks per round: two per worker wavefront
 struct zz_l6m_params {
     zz_packet_params pk;
     uint32_t* m;            // one word per input byte of the packets k0 .. k1-1
+    uint16_t* chains;       // gridDim.x * 32768 * DEPTH entries
     uint32_t* work;         // packets handed out beyond the first gridDim.x (zero at launch)
     uint32_t k0, k1;
 };
 
-template <int DEPTH>
-__device__ __forceinline__ void l6m_match_block(const uint16_t* sorted, const uint8_t* src, const uint8_t* end, uint32_t target,
-                                                uint32_t b, uint32_t place, uint32_t* mrow)
+typedef __attribute__((address_space(3))) const uint8_t* zz_lds_bytes;
+// 16 bytes at any byte offset of an LDS image, as two little-endian words
+__device__ __forceinline__ void lds_gather16(zz_lds_bytes base, uint32_t off, uint64_t& lo, uint64_t& hi)
 {
-    const int lane = lane_id();
-    const uint32_t q = (b << 6) + (uint32_t)lane;
-    const bool act = q < target;
-    const uint32_t qa = act ? q : 0u;
-    uint16_t c[DEPTH];
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) c[k] = sorted[ZZ_L6_PAD + place - DEPTH + k];     // nearest last
-    uint64_t w, w2, cw[DEPTH], cw2[DEPTH];
-    uint32_t dist[DEPTH];
-    ld128<false>(src + qa, end, w, w2);                                     // q + 16 <= n: inside the data
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) {                                       // k = 0: the nearest
-        const int32_t cp = (int32_t)c[DEPTH - 1 - k] - (int32_t)ZZ_L6_BIAS;
-        const uint32_t d = q - (uint32_t)cp;                                // 0 < d < 32768: a candidate
-        const bool ok = act && (d - 1u) < 32767u;
-        dist[k] = ok ? d : 0u;
-        ld128<false>(src + (ok ? cp : (int32_t)qa), end, cw[k], cw2[k]);
+    typedef __attribute__((address_space(3))) const uint64_t* p8;
+    const uint32_t a = off & ~7u, sh = (off & 3u) << 3;
+    const bool up = (off & 4u) != 0;
+    const uint64_t x0 = *(p8)(base + a), x1 = *(p8)(base + a + 8), x2 = *(p8)(base + a + 16);
+    const uint32_t x0l = (uint32_t)x0, x0h = (uint32_t)(x0 >> 32), x1l = (uint32_t)x1, x1h = (uint32_t)(x1 >> 32), x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
+    const uint32_t e0 = up ? x0h : x0l, e1 = up ? x1l : x0h, e2 = up ? x1h : x1l, e3 = up ? x2l : x1h, e4 = up ? x2h : x2l;
+    const uint32_t w0 = __builtin_amdgcn_alignbit(e1, e0, sh), w1 = __builtin_amdgcn_alignbit(e2, e1, sh);
+    const uint32_t w2 = __builtin_amdgcn_alignbit(e3, e2, sh), w3 = __builtin_amdgcn_alignbit(e4, e3, sh);
+    lo = ((uint64_t)w1 << 32) | w0;
+    hi = ((uint64_t)w3 << 32) | w2;
+}
+
+// the same in two steps, for a candidate: most differ from the position within their first eight bytes, and the third read
+// and half of the shifting are only for those that do not. Returns the number of equal leading bytes, 16 = all.
+__device__ __forceinline__ uint32_t lds_match16(zz_lds_bytes base, uint32_t off, uint64_t w, uint64_t w2)
+{
+    typedef __attribute__((address_space(3))) const uint64_t* p8;
+    const uint32_t a = off & ~7u, sh = (off & 3u) << 3;
+    const bool up = (off & 4u) != 0;
+    const uint64_t x0 = *(p8)(base + a), x1 = *(p8)(base + a + 8);
+    const uint32_t x0l = (uint32_t)x0, x0h = (uint32_t)(x0 >> 32), x1l = (uint32_t)x1, x1h = (uint32_t)(x1 >> 32);
+    const uint32_t e0 = up ? x0h : x0l, e1 = up ? x1l : x0h, e2 = up ? x1h : x1l;
+    const uint32_t d0 = __builtin_amdgcn_alignbit(e1, e0, sh) ^ (uint32_t)w, d1 = __builtin_amdgcn_alignbit(e2, e1, sh) ^ (uint32_t)(w >> 32);
+    const uint32_t f0 = ffbl_or_ones(d0), f1 = add_sat_k<32>(ffbl_or_ones(d1));
+    uint32_t bits = f0 < f1 ? f0 : f1;                                   // >= 64: the first eight bytes are equal
+    if (bits >= 64u) {
+        const uint64_t x2 = *(p8)(base + a + 16);
+        const uint32_t x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
+        const uint32_t e3 = up ? x2l : x1h, e4 = up ? x2h : x2l;
+        const uint32_t d2 = __builtin_amdgcn_alignbit(e3, e2, sh) ^ (uint32_t)w2, d3 = __builtin_amdgcn_alignbit(e4, e3, sh) ^ (uint32_t)(w2 >> 32);
+        const uint32_t f2 = ffbl_or_ones(d2), f3 = add_sat_k<32>(ffbl_or_ones(d3));
+        const uint32_t t = f2 < f3 ? f2 : f3;
+        bits = 64u + (t < 64u ? t : 64u);
     }
-    uint32_t best = 0, bdist = 0;
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) {
-        uint32_t len = equal_bits128(w ^ cw[k], w2 ^ cw2[k], 128u) >> 3;
-        if (!dist[k]) len = 0;
-        if (len > best) { best = len; bdist = dist[k]; }
-    }
-    if (best < 4) best = 0;
-    // lazy: the next position's length (lane 63 never defers)
-    const uint32_t nxt = (uint32_t)__shfl_down((int)best, 1);
-    const bool defer = best != 0 && best < ZZ_L6_CAP && lane != 63 && nxt > best;
-    if (act) mrow[q] = (best != 0 && !defer) ? (best << 16) | bdist : 0u;
+    return bits >> 3;
 }
 
 template <int DEPTH>
 __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
 {
     const zz_packet_params& P = Q.pk;
-    __shared__ __attribute__((aligned(16))) uint16_t sorted[ZZ_L6_SORT_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint16_t sorted[ZZ_L6_SORT_ENTRIES];     // step 3: the window and the packet, as bytes
     __shared__ __attribute__((aligned(16))) uint32_t Tw[ZZ_HASH_SIZE / 2 + 4];      // 8192 16-bit counters, two per word (+ the one lanes without a position use)
     __shared__ __attribute__((aligned(16))) uint32_t ring[2][ZZ_L6M_ROUND][ZZ_WAVE];
     __shared__ uint32_t wtot[ZZ_L6M_THREADS / ZZ_WAVE];
     __shared__ uint32_t nextk;
-    uint16_t* const T = (uint16_t*)Tw;
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
     const uint32_t wave = uniform(tid >> 6);
-    const uint64_t below_me = (1ull << lane) - 1;
+    uint16_t* const chains = Q.chains + (uint64_t)blockIdx.x * (32768u * DEPTH);
     ZZ_PROF_DECL
 
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);        // the placer's chain is the serial part of a packet
     uint32_t k = Q.k0 + blockIdx.x;
     while (k < Q.k1) {
         const uint64_t off = (uint64_t)k * P.packet_size;
@@ -126,7 +135,6 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
         const bool is_final = P.last_is_final && k == P.npk - 1;
         const uint32_t n = is_final ? len : len - 1;      // bytes of the compressing AddData (zz_level2.h)
         const uint8_t* src = P.src + off;
-        const uint8_t* end = P.src + P.n;
         const uint64_t before = P.halo + off;
         const int32_t W = (int32_t)(before < P.warm ? before : P.warm);
         const uint32_t target = l6_target(n);
@@ -143,15 +151,15 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
             }
             __syncthreads();
             ZZ_T(6);
-            for (int32_t p0 = lo + (int32_t)tid; p0 < hi; p0 += 4 * (int32_t)ZZ_L6M_THREADS) {      // four loads in flight
-                uint32_t v[4];
+            for (int32_t p0 = lo + (int32_t)tid; p0 < hi; p0 += 8 * (int32_t)ZZ_L6M_THREADS) {      // eight loads in flight
+                uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int32_t pos = p0 + u * (int32_t)ZZ_L6M_THREADS;
                     v[u] = load32(src + (pos < hi ? pos : lo));
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int32_t pos = p0 + u * (int32_t)ZZ_L6M_THREADS;
                     const uint32_t h = l6_hash4(v[u]);
                     if (pos < hi) atomicAdd(&Tw[h >> 1], 1u << ((h & 1u) << 4));
@@ -186,46 +194,47 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
             auto fetch = [&](uint32_t t) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const uint32_t bi = t * ZZ_L6M_ROUND + 2u * (wave - 1u) + (uint32_t)u;
+                    const uint32_t bi = t * ZZ_L6M_ROUND + 2u * (wave - ZZ_L6M_PLACERS) + (uint32_t)u;
                     const int32_t pos = g0 + (int32_t)(bi << 6) + lane;
                     vnext[u] = load32(src + ((bi < nblk && pos >= lo && pos < hi) ? pos : lo));
                 }
             };
-            if (wave != 0) fetch(0);
-            for (uint32_t t = 0; t <= NR + 1; ++t) {
-                if (wave == 0) {
-                    if (t >= 1 && t <= NR) {
-                        // The placer. The LDS serves the lanes of one instruction that add to one address in ascending lane
-                        // order, and a wavefront's LDS instructions in issue order (tools/ubench_lds_atomic_order.hip, and the
-                        // library's own zz_debug_lds_atomic_order behind a GPU test): ds_add_rtn on the bucket's counter IS the
-                        // place of every position, block after block -- no ranking of equal hashes, no wait between blocks.
-                        const uint32_t r0 = (t - 1) * ZZ_L6M_ROUND;
-                        const uint32_t cnt = nblk - r0 < ZZ_L6M_ROUND ? nblk - r0 : ZZ_L6M_ROUND;
-                        uint32_t* const slots = &ring[(t - 1) & 1][0][0];
-                        const uint32_t val0 = (uint32_t)(g0 + (int32_t)(r0 << 6) + lane + (int32_t)ZZ_L6_BIAS);
-                        uint32_t inf[ZZ_L6M_ROUND], old[ZZ_L6M_ROUND];
+            // the placer's round. FULL: every lane of every block has a position (all rounds but the first and the last)
+            auto place_round = [&](uint32_t r, auto fulltag) {
+                constexpr bool FULL = decltype(fulltag)::value;
+                const uint32_t r0 = r * ZZ_L6M_ROUND;
+                const uint32_t cnt = nblk - r0 < ZZ_L6M_ROUND ? nblk - r0 : ZZ_L6M_ROUND;
+                uint32_t* const slots = &ring[r & 1][0][0];
+                const uint32_t val0 = (uint32_t)(g0 + (int32_t)(r0 << 6) + lane + (int32_t)ZZ_L6_BIAS);
+                uint32_t inf[ZZ_L6M_ROUND], old[ZZ_L6M_ROUND];
 #pragma unroll
-                        for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) inf[s] = slots[s * ZZ_WAVE + (uint32_t)lane];
+                for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) inf[s] = slots[s * ZZ_WAVE + (uint32_t)lane];
 #pragma unroll
-                        for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s)
-                            if (s < cnt) old[s] = atomicAdd((uint32_t*)((uint8_t*)Tw + (inf[s] & 0xFFFFu)), 1u << (inf[s] >> 16));
-                        ZZ_T(15);
+                for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s)
+                    if (FULL || s < cnt) old[s] = atomicAdd((uint32_t*)((uint8_t*)Tw + (inf[s] & 0xFFFFu)), 1u << (inf[s] >> 16));
 #pragma unroll
-                        for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) {
-                            if (s < cnt) {
-                                const uint32_t place = __builtin_amdgcn_ubfe(old[s], inf[s] >> 16, 16);
-                                if ((int32_t)inf[s] >= 0) {                        // (a lane without a position added to a counter of its own)
-                                    sorted[ZZ_L6_PAD + place] = (uint16_t)(val0 + (s << 6));
-                                    slots[s * ZZ_WAVE + (uint32_t)lane] = place;
-                                }
-                            }
+                for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) {
+                    if (FULL || s < cnt) {
+                        const uint32_t place = __builtin_amdgcn_ubfe(old[s], inf[s] >> 16, 16);
+                        if (FULL || (int32_t)inf[s] >= 0) {                        // (a lane without a position added to a counter of its own)
+                            sorted[ZZ_L6_PAD + place] = (uint16_t)(val0 + (s << 6));
+                            slots[s * ZZ_WAVE + (uint32_t)lane] = place;
                         }
                     }
-                    ZZ_T(14);
+                }
+            };
+            if (wave >= ZZ_L6M_PLACERS) fetch(0);
+            else __builtin_amdgcn_s_setprio(3);        // the placers' streams of adds are the serial part of a packet
+            for (uint32_t t = 0; t <= NR + 1; ++t) {
+                if (wave < ZZ_L6M_PLACERS) {
+                    if (t >= 1 && t <= NR) {
+                        if (t >= 2 && t * ZZ_L6M_ROUND < nblk) place_round(t - 1, std::true_type());
+                        else place_round(t - 1, std::false_type());
+                    }
                 } else {
-                    const uint32_t s0 = 2u * (wave - 1u);
+                    const uint32_t s0 = 2u * (wave - ZZ_L6M_PLACERS);
                     uint32_t place[2] = { 0, 0 };
-                    uint32_t mb[2] = { ~0u, ~0u };              // the packet block to match (round t-2), ~0: none
+                    uint32_t mb[2] = { ~0u, ~0u };              // the packet block whose chains to copy (round t-2), ~0: none
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const uint32_t bi = (t - 2) * ZZ_L6M_ROUND + s0 + (uint32_t)u;
@@ -245,12 +254,81 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
                         fetch(t + 1);
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        if (mb[u] != ~0u) l6m_match_block<DEPTH>(sorted, src, end, target, mb[u], place[u], mrow);
+                    for (int u = 0; u < 2; ++u) {
+                        if (mb[u] != ~0u) {
+                            const uint32_t q = (mb[u] << 6) + (uint32_t)lane;
+                            if (q < target) {
+                                uint16_t c[DEPTH];
+#pragma unroll
+                                for (int i = 0; i < DEPTH; ++i) c[i] = sorted[ZZ_L6_PAD + place[u] - DEPTH + i];     // nearest last
+                                __builtin_memcpy(chains + (uint64_t)q * DEPTH, c, 2 * DEPTH);
+                            }
+                        }
+                    }
                 }
                 __syncthreads();
-                if (t * ZZ_L6M_ROUND < (Wr >> 6) + 2 * ZZ_L6M_ROUND) { ZZ_T(9); } else { ZZ_T(12); }   // rounds without / with matching
+                if (t * ZZ_L6M_ROUND < (Wr >> 6) + 2 * ZZ_L6M_ROUND) { ZZ_T(9); } else { ZZ_T(12); }   // rounds without / with chain copies
             }
+            if (wave < ZZ_L6M_PLACERS) __builtin_amdgcn_s_setprio(0);
+            // ---- 3: the window and the packet into LDS (position p at byte 32768 + p: an array entry IS its position's offset) ----
+            {
+                uint8_t* const L = (uint8_t*)sorted;
+                const uint64_t avail64 = (uint64_t)((P.src + P.n) - src);
+                const int32_t avail = (int32_t)(avail64 < 65536u ? avail64 : 65536u);           // bytes readable from src on
+                const int32_t c0 = (32768 - W) >> 4, c1 = (32768 + (int32_t)n + 8 + 15) >> 4;
+                for (int32_t c = c0 + (int32_t)tid; c < c1; c += (int32_t)ZZ_L6M_THREADS) {
+                    const int32_t p = (c << 4) - 32768;
+                    uint4 v;
+                    if (p >= -W && p + 16 <= avail) __builtin_memcpy(&v, src + p, 16);
+                    else {
+                        uint8_t bts[16];
+                        for (int i = 0; i < 16; ++i) bts[i] = (p + i >= -W && p + i < avail) ? src[p + i] : (uint8_t)0;
+                        __builtin_memcpy(&v, bts, 16);
+                    }
+                    *(uint4*)(L + ((uint32_t)c << 4)) = v;
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the chains: no stale line of the previous packet's in the L1
+            ZZ_T(15);
+            {
+                const zz_lds_bytes L = (zz_lds_bytes)(const uint8_t*)sorted;
+                const uint32_t npb = (target + 63u) >> 6;
+                struct chain_t { uint16_t c[DEPTH]; };
+                auto ldchain = [&](uint32_t b) -> chain_t {
+                    const uint32_t q = (b << 6) + (uint32_t)lane;
+                    chain_t ch;
+                    __builtin_memcpy(ch.c, chains + (uint64_t)(q < target ? q : 0u) * DEPTH, 2 * DEPTH);
+                    return ch;
+                };
+                chain_t nextc = ldchain(wave);                                  // (one block's chains ahead of their use)
+                for (uint32_t b = wave; b < npb; b += ZZ_L6M_THREADS / ZZ_WAVE) {
+                    const uint32_t q = (b << 6) + (uint32_t)lane;
+                    const bool act = q < target;
+                    const uint32_t qa = act ? q : 0u;
+                    const chain_t cur = nextc;
+                    nextc = ldchain(b + ZZ_L6M_THREADS / ZZ_WAVE < npb ? b + ZZ_L6M_THREADS / ZZ_WAVE : b);
+                    const uint16_t* c = cur.c;
+                    uint64_t w, w2;
+                    lds_gather16(L, ZZ_L6_BIAS + qa, w, w2);                        // q + 16 <= n: inside the data
+                    uint32_t best = 0, bdist = 0;
+#pragma unroll
+                    for (int i = 0; i < DEPTH; ++i) {                               // i = 0: the nearest
+                        const uint32_t co = c[DEPTH - 1 - i];                      // the candidate's offset in the image
+                        const uint32_t d = (ZZ_L6_BIAS + q) - co;                   // 0 < d < 32768: a candidate
+                        if (act && (d - 1u) < 32767u) {
+                            const uint32_t ln = lds_match16(L, co, w, w2);
+                            if (ln > best) { best = ln; bdist = d; }
+                        }
+                    }
+                    if (best < 4) best = 0;
+                    // lazy: the next position's length (lane 63 never defers)
+                    const uint32_t nxt = (uint32_t)__shfl_down((int)best, 1);
+                    const bool defer = best != 0 && best < ZZ_L6_CAP && lane != 63 && nxt > best;
+                    if (act) mrow[q] = (best != 0 && !defer) ? (best << 16) | bdist : 0u;
+                }
+            }
+            ZZ_T(14);
         }
         __syncthreads();
         if (tid == 0) nextk = Q.k0 + gridDim.x + atomicAdd(Q.work, 1u);
