@@ -182,6 +182,70 @@ extern "C" int zz_debug_occupancy(int level)
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
 }
+// diagnostic (not part of the public header): does the LDS serve the lanes of one wavefront instruction that add to one
+// address in ascending lane order, and one wavefront's instructions in issue order? k_l6_matches' counting sort takes its places
+// from exactly that (zz_level6.h). Runs `trials` pairs of 64-key blocks per wavefront in 16-wavefront workgroups on every CU, keys
+// drawn with many duplicates (shared dwords, shared banks, one heavy key, all equal ...); *bad = the number of returned counts
+// that differ from the lane-ascending, block-ascending ones (0 on gfx950).
+__global__ __launch_bounds__(1024) void k_lds_order_probe(uint32_t seed, uint32_t trials, unsigned long long* bad)
+{
+    __shared__ uint32_t T[16][256];                // 512 packed 16-bit counters per wavefront
+    __shared__ uint16_t K[16][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = lane; i < 256; i += 64) T[wave][i] = 0;
+    uint32_t x = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+    unsigned long long nbad = 0;
+    for (uint32_t t = 0; t < trials; ++t) {
+        uint32_t k[2];
+        for (int u = 0; u < 2; ++u) {
+            x = x * 1664525u + 1013904223u;
+            const uint32_t r = x >> 8;
+            switch ((t + blockIdx.x) & 7u) {
+            case 0: k[u] = r % 512u; break;                          // few duplicates
+            case 1: k[u] = r % 16u; break;                           // many
+            case 2: k[u] = r % 3u; break;                            // three values, two of them in one dword
+            case 3: k[u] = 7u; break;                                // all the same
+            case 4: k[u] = (r % 8u) * 64u; break;                    // one bank, different addresses
+            case 5: k[u] = (r % 4u) * 64u + ((r >> 5) & 1u); break;  // one bank, halves of a dword
+            case 6: k[u] = (lane & 1) ? 5u : r % 512u; break;        // one heavy key among light ones
+            default: k[u] = r % 40u; break;
+            }
+            K[wave][u * 64 + lane] = (uint16_t)k[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // two blocks back to back, no wait between them
+        const uint32_t oa = atomicAdd(&T[wave][k[0] >> 1], 1u << ((k[0] & 1u) << 4));
+        const uint32_t ob = atomicAdd(&T[wave][k[1] >> 1], 1u << ((k[1] & 1u) << 4));
+        const uint32_t ra = (oa >> ((k[0] & 1u) << 4)) & 0xFFFFu, rb = (ob >> ((k[1] & 1u) << 4)) & 0xFFFFu;
+        uint32_t wa = 0, wb = 0;                                     // what lane order gives
+        for (int i = 0; i < 64; ++i) {
+            if (i < lane && K[wave][i] == k[0]) ++wa;
+            if (K[wave][i] == k[1]) ++wb;                            // all of block A come first ...
+            if (i < lane && K[wave][64 + i] == k[1]) ++wb;           // ... then the lower lanes of block B
+        }
+        if (ra != wa) ++nbad;
+        if (rb != wb) ++nbad;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        atomicSub(&T[wave][k[0] >> 1], 1u << ((k[0] & 1u) << 4));
+        atomicSub(&T[wave][k[1] >> 1], 1u << ((k[1] & 1u) << 4));
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+extern "C" int zz_debug_lds_atomic_order(zz_ctx* c, uint32_t trials, unsigned long long* bad, unsigned long long* checked)
+{
+    if (!c || !bad) return ZZ_E_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_lds_order_probe, dim3(512), dim3(1024), 0, 0, 0x5EEDu, trials, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(bad, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    if (checked) *checked = 512ull * 1024ull * 2ull * trials;
+    return ZZ_OK;
+}
 // diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
 extern "C" int zz_debug_read_prof(zz_ctx* c, unsigned long long out[16])
 {
