@@ -534,13 +534,13 @@ def test_warm_window_level1(gpu, oracle, corpus, warm):
 def test_lds_serves_equal_addresses_in_lane_order(gpu):
     """What k_l6_matches' counting sort takes its places from (zz_level6.h): a returning LDS add hands the lanes of one
     wavefront instruction that hit one counter their counts in ascending lane order, and one wavefront's instructions theirs
-    in issue order. Not in the ISA manual, so checked on the device this runs on: 134 million returned counts, keys with
-    every kind of duplicate (one dword, one bank, one heavy key, all equal), 16 wavefronts per workgroup on every CU."""
+    in issue order -- and the masked exchange (ds_mskor) the parsers insert with behaves the same. Not in the ISA manual, so
+    checked on the device this runs on: 335 million values, keys with every kind of duplicate (one dword, one bank, one heavy key, all equal), 16 wavefronts per workgroup on every CU."""
     import ctypes
     ctx = zz.Context(0)
     bad, checked = ctypes.c_uint64(1), ctypes.c_uint64(0)
     assert zz.lib.zz_debug_lds_atomic_order(ctx._h, 128, ctypes.byref(bad), ctypes.byref(checked)) == 0
-    assert checked.value == 512 * 1024 * 2 * 128 and bad.value == 0, (bad.value, checked.value)
+    assert checked.value == 512 * 1024 * 5 * 128 and bad.value == 0, (bad.value, checked.value)
 
 
 def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):

@@ -229,6 +229,40 @@ __global__ __launch_bounds__(1024) void k_lds_order_probe(uint32_t seed, uint32_
         atomicSub(&T[wave][k[0] >> 1], 1u << ((k[0] & 1u) << 4));
         atomicSub(&T[wave][k[1] >> 1], 1u << ((k[1] & 1u) << 4));
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // the same for the masked exchange the level-1 and level-2 parsers insert with (zz_level1.h): every lane puts lane + 1 into
+        // its key's 16-bit half and must get back what the nearest lower lane with that key put there (0: none); afterwards the
+        // half holds the highest lane's; and a non-returning one under a lane mask leaves the highest masked lane's
+        {
+            const uint32_t sh = (k[0] & 1u) << 4;
+            const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&T[wave][k[0] >> 1];
+            uint32_t old;
+            asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(0xFFFFu << sh), "v"((uint32_t)(lane + 1) << sh) : "memory");
+            uint32_t wprev = 0, whigh = 0, wmask = 0;
+            const uint64_t msk = ((uint64_t)x << 32 | (x * 2246822519u)) | (t & 1u ? 0ull : ~0ull >> (x & 63u));   // some lanes, or most
+            for (int i = 0; i < 64; ++i)
+                if (K[wave][i] == k[0]) {
+                    if (i < lane) wprev = (uint32_t)i + 1;
+                    whigh = (uint32_t)i + 1;
+                    if ((msk >> i) & 1) wmask = (uint32_t)i + 65;
+                }
+            if (((old >> sh) & 0xFFFFu) != wprev) ++nbad;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (((T[wave][k[0] >> 1] >> sh) & 0xFFFFu) != whigh) ++nbad;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            ((uint16_t*)T[wave])[k[0]] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const uint64_t mskw = ((uint64_t)readlane((uint32_t)(msk >> 32), 0) << 32) | readlane((uint32_t)msk, 0);   // one mask for the wavefront
+            uint32_t wm2 = 0;
+            for (int i = 0; i < 64; ++i) if (K[wave][i] == k[0] && ((mskw >> i) & 1)) wm2 = (uint32_t)i + 65;
+            (void)wmask;
+            if ((mskw >> lane) & 1)
+                asm volatile("ds_mskor_b32 %0, %1, %2" :: "v"(addr), "v"(0xFFFFu << sh), "v"((uint32_t)(lane + 65) << sh) : "memory");
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (((T[wave][k[0] >> 1] >> sh) & 0xFFFFu) != wm2) ++nbad;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            ((uint16_t*)T[wave])[k[0]] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
     }
     if (nbad) atomicAdd(bad, nbad);
 }
@@ -243,7 +277,7 @@ extern "C" int zz_debug_lds_atomic_order(zz_ctx* c, uint32_t trials, unsigned lo
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(bad, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipFree(d));
-    if (checked) *checked = 512ull * 1024ull * 2ull * trials;
+    if (checked) *checked = 512ull * 1024ull * 5ull * trials;
     return ZZ_OK;
 }
 // diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
