@@ -233,7 +233,7 @@ def main():
     if args.warm:
         ctx.set_warm_window(args.warm)
     if args.level > 3:
-        ctx.set_extended_levels(True)      # levels 4..6: beyond the reference (level-2 encoder + warm window), SURVEY.md 8f.2
+        ctx.set_extended_levels(True)      # levels 4..6: beyond the reference (chains, lazy matching, package-merge), SURVEY.md 8f.2
 
     n = args.mib << 20                 # bytes per rank (weak scaling)
     total_n = n * world

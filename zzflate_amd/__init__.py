@@ -234,8 +234,9 @@ class Context:
         _check(lib.zz_ctx_set_warm_window(self._h, nbytes))
 
     def set_extended_levels(self, on=True):
-        """Accept levels 4, 5, 6 (beyond the reference, which rejects them): the level-2 encoder with a warm window of
-        4, 16, 32 KiB. Off by default, so that level > 3 stays the reference's error."""
+        """Accept levels 4, 5, 6 (beyond the reference, which rejects them): hash chains of depth 2 / 4 / 8 over a window of
+        8 / 32 / 32 KiB, one-step lazy matching, package-merge code lengths. Off by default, so that level > 3
+        stays the reference's error."""
         _check(lib.zz_ctx_set_extended_levels(self._h, 1 if on else 0))
 
     def enable_timing(self, on=True):
