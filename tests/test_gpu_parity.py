@@ -540,7 +540,7 @@ def test_lds_serves_equal_addresses_in_lane_order(gpu):
     ctx = zz.Context(0)
     bad, checked = ctypes.c_uint64(1), ctypes.c_uint64(0)
     assert zz.lib.zz_debug_lds_atomic_order(ctx._h, 128, ctypes.byref(bad), ctypes.byref(checked)) == 0
-    assert checked.value == 512 * 1024 * 5 * 128 and bad.value == 0, (bad.value, checked.value)
+    assert checked.value == 512 * 1024 * 6 * 128 and bad.value == 0, (bad.value, checked.value)
 
 
 def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):

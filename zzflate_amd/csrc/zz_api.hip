@@ -262,6 +262,19 @@ __global__ __launch_bounds__(1024) void k_lds_order_probe(uint32_t seed, uint32_
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             ((uint16_t*)T[wave])[k[0]] = 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // plain 16-bit stores: two blocks back to back; the slot must end up with the LAST store's highest lane (the warm
+            // window's pre-hash enters its positions with nothing else: zz_level1.h warm_prehash)
+            ((uint16_t*)T[wave])[k[0]] = (uint16_t)(lane + 1);
+            ((uint16_t*)T[wave])[k[1]] = (uint16_t)(lane + 65);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            uint32_t ws = 0;
+            for (int i = 0; i < 64; ++i) if (K[wave][i] == k[0]) ws = (uint32_t)i + 1;
+            for (int i = 0; i < 64; ++i) if (K[wave][64 + i] == k[0]) ws = (uint32_t)i + 65;
+            if (((uint16_t*)T[wave])[k[0]] != ws) ++nbad;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            ((uint16_t*)T[wave])[k[0]] = 0;
+            ((uint16_t*)T[wave])[k[1]] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
     }
     if (nbad) atomicAdd(bad, nbad);
@@ -277,7 +290,7 @@ extern "C" int zz_debug_lds_atomic_order(zz_ctx* c, uint32_t trials, unsigned lo
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(bad, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIPCHK(hipFree(d));
-    if (checked) *checked = 512ull * 1024ull * 5ull * trials;
+    if (checked) *checked = 512ull * 1024ull * 6ull * trials;
     return ZZ_OK;
 }
 // diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
@@ -299,7 +312,7 @@ extern "C" int zz_ctx_set_warm_window(zz_ctx* c, uint32_t bytes)
     return ZZ_OK;
 }
 // levels beyond the reference. Off by default, so that the entry points keep the reference's error
-// convention for level > 3; on: levels 4, 5, 6 = the level-2 encoder with a warm window of 4, 16, 32 KiB.
+// convention for level > 3; on: levels 4, 5, 6 = chains of depth 2 / 4 / 8, lazy matching, package-merge (zz_level6.h).
 extern "C" int zz_ctx_set_extended_levels(zz_ctx* c, int on)
 {
     if (!c) { set_err("null ctx"); return ZZ_E_ARG; }

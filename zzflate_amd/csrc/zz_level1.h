@@ -735,16 +735,10 @@ __device__ __forceinline__ l1_pk l1_packet_of(const zz_packet_params& P, uint32_
 // so nothing is serialised; the stream is not the reference's threaded stream any more (a separate flag), it is
 // pinned by the oracle's restatement of this very rule and by inflate.
 // Warm window: every position of the W bytes in front of the packet goes into the (empty) table under its key -- the three
-// bytes at position + keyoff --, and per hash the HIGHEST position stays. Eight groups of 64 positions per trip. Two things
-// took the time in round 2 (20 % of a level-1 packet at W = 32 KiB), both latencies: the trip's eight loads (the window comes
-// from the Infinity Cache, ~2 us) -- now the NEXT trip's loads are requested before this trip's are used --, and one LDS round
-// trip per group for the read-back -- now the eight groups store back to back (in order: later groups overwrite earlier ones),
-// then read back together; a lane that sees a lower position than its own stores again in the next round (a value only ever
-// rises, so the rounds end with the maximum in place; one or two rounds on text). (Also tried in round 3: one pass with the
-// six-ballot same-hash sets instead of the retry rounds -- 92.6 vs 95.3 GB/s: profiles/README.md.)
-// MASKFREE: a settled lane stores to and reads from a spare slot instead of sitting out under a lane mask (every masked region is
-// three scalar instructions, sixteen of them per round): +3 % at level 1; level 2's kernel has no registers to spare for the
-// address selects (it spills: -4 %) and keeps the masks.
+// bytes at position + keyoff --, and per hash the HIGHEST position stays. Eight groups of 64 positions per trip, the next trip's
+// loads requested before this trip's are used (the window comes from the Infinity Cache, ~2 us).
+// MASKFREE: a lane without a position stores to a spare slot instead of sitting out under a lane mask (every masked region is
+// three scalar instructions); level 2's kernel has no registers to spare for the address selects and keeps the masks.
 template <uint32_t BIAS, bool MASKFREE>
 __device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, int32_t W, const uint8_t* end, int keyoff, uint32_t spare)
 {
@@ -756,35 +750,35 @@ __device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, in
             w4[u] = (g < 0 && pos < 0) ? load32_safe(src + pos + keyoff, end) : 0u;
         }
     };
+    // The LDS serves the lanes of one store that hit one address in ascending lane order, and one wavefront's stores in issue
+    // order (zz_debug_lds_atomic_order, under a GPU test): storing the positions block after block, ascending, leaves the
+    // highest position of every hash in place -- no read-back, no retry rounds (round 3's earlier form: 104.1 GB/s at 32 KiB).
     auto enter = [&](int32_t g, const uint32_t (&w4)[8]) {
-        uint32_t hh[8], val[8];
-        uint32_t pend = 0;                                          // bit u: this lane's position of group u is not settled
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int32_t pos = g + u * ZZ_WAVE + lane;
-            val[u] = (uint32_t)(pos + 1 + (int32_t)BIAS);
-            hh[u] = calc_hash3(w4[u]);
-            pend |= pos < 0 ? 1u << u : 0u;
-        }
-        while (ballot(pend != 0)) {
-            uint32_t still = 0;
-            if (MASKFREE) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) T[(pend & (1u << u)) ? hh[u] : spare] = (uint16_t)val[u];
-                ZZ_WAVE_SYNC();
-#pragma unroll
-                for (int u = 0; u < 8; ++u) still |= (T[(pend & (1u << u)) ? hh[u] : spare] < val[u] ? 1u << u : 0u) & pend;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (pend & (1u << u)) T[hh[u]] = (uint16_t)val[u];
-                ZZ_WAVE_SYNC();
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if ((pend & (1u << u)) && T[hh[u]] < val[u]) still |= 1u << u;
-            }
-            pend = still;
-            ZZ_WAVE_SYNC();
+            const uint32_t hh = calc_hash3(w4[u]);
+            if (MASKFREE) T[pos < 0 ? hh : spare] = (uint16_t)(pos + 1 + (int32_t)BIAS);
+            else if (pos < 0) T[hh] = (uint16_t)(pos + 1 + (int32_t)BIAS);
         }
     };
+    if (MASKFREE) {
+        // (a trip is eight stores now: three trips' loads in flight to cover the window's way from the Infinity Cache)
+        uint32_t wa[8], wb[8], wc[8];
+        request(-W, wa);
+        request(-W + 8 * ZZ_WAVE, wb);
+        for (int32_t g = -W; g < 0; g += 24 * ZZ_WAVE) {
+            request(g + 16 * ZZ_WAVE, wc);
+            enter(g, wa);
+            if (g + 8 * ZZ_WAVE >= 0) break;
+            request(g + 24 * ZZ_WAVE, wa);
+            enter(g + 8 * ZZ_WAVE, wb);
+            if (g + 16 * ZZ_WAVE >= 0) break;
+            request(g + 32 * ZZ_WAVE, wb);
+            enter(g + 16 * ZZ_WAVE, wc);
+        }
+        return;
+    }
     uint32_t wa[8], wb[8];
     request(-W, wa);
     for (int32_t g = -W; g < 0; g += 16 * ZZ_WAVE) {
