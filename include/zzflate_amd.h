@@ -83,7 +83,8 @@ int zz_ctx_set_warm_window(zz_ctx* ctx, uint32_t bytes);
  * of 8 / 32 / 32 KiB in front of every packet, one-step lazy matching, one dynamic block per packet with code lengths by
  * package-merge. Not comparable with any reference stream; defined by the oracle, checked bit for bit against it,
  * by inflate, and by ratio (mixed corpus: 0.461 at level 3, 0.422 at level 6). Shards must make the window available as their
- * halo. Env ZZFLATE_EXTENDED_LEVELS=1 switches them on for the host entry points. */
+ * halo. Workspace: 4 bytes per input byte of a call, for at most 1 GiB of input at a time (larger calls go through in batches),
+ * and 128 MiB. Env ZZFLATE_EXTENDED_LEVELS=1 switches them on for the host entry points. */
 int zz_ctx_set_extended_levels(zz_ctx* ctx, int on);
 
 /* ---- sizes -------------------------------------------------------------------------------------- */
