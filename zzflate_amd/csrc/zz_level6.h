@@ -46,16 +46,17 @@ __device__ __forceinline__ uint32_t l6_trips(uint32_t n) { return (l6_target(n) 
 // One packet per workgroup of 16 wavefronts, 160 KiB of LDS. Per packet:
 //   1  all: array and counters to zero; histogram of the hashes of positions -W .. target-1 (LDS atomics on the packed 16-bit
 //      counters); exclusive scan -> every bucket's first place;
-//   2  the sort, in rounds of 30 blocks of 64 positions, ascending, one workgroup barrier per round, three rounds in flight:
+//   2  the sort, in rounds of 30 blocks of 64 positions, ascending, one workgroup barrier per round, four rounds in flight:
 //      - the 15 WORKER wavefronts prepare round t: the hashes of their two blocks, as the counter's address and shift -> ring;
-//      - wavefront 0, the PLACER, takes round t-1 from the ring: one returning add per block on the buckets' counters. The LDS
-//        serves the lanes of one instruction that add to one address in ascending lane order, and one wavefront's instructions
-//        in issue order (tools/ubench_lds_atomic_order.hip; zz_debug_lds_atomic_order behind a GPU test), so what the add
-//        returns IS the position's place: no ranking of equal hashes, no wait between blocks. sorted[place] = position; the
-//        place goes back into the ring slot;
-//      - the workers take the places of round t-2 from the ring and, for the packet's own positions, copy the chain -- the
-//        DEPTH entries in front of the place; all earlier positions stand in the array by now, later ones land behind them
-//        or in other buckets -- to the workgroup's scratch in global memory (2*DEPTH bytes per position, coalesced);
+//      - wavefront 0, the PLACER, takes round t-1 from the ring: one returning add per block on the buckets' counters, and what
+//        it returned back into the ring slot -- nothing else. The LDS serves the lanes of one instruction that add to one
+//        address in ascending lane order, and one wavefront's instructions in issue order (tools/ubench_lds_atomic_order.hip;
+//        zz_debug_lds_atomic_order behind a GPU test), so what the add returns IS the position's place: no ranking of equal
+//        hashes, no wait between blocks;
+//      - the workers take round t-2's returns from the ring: sorted[place] = position;
+//      - and, for the packet's own positions of round t-3, copy the chain -- the DEPTH entries in front of the place; all
+//        earlier positions stand in the array since the barrier before, later ones land behind them or in other buckets -- to
+//        the workgroup's scratch in global memory (2*DEPTH bytes per position, coalesced);
 //   3  the array is dead: the window and the packet (<= 64 KiB) take its place in LDS, and all 16 wavefronts compare -- per
 //      position 16 bytes against 16 bytes at each candidate, gathered from LDS (three 8-byte reads and a funnel shift each; from
 //      global memory every candidate was a 128-byte line for 16 bytes of it, and the load path, not the CU, set the pace);
@@ -191,83 +192,78 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
             const uint32_t nblk = (Wr + ((target + 63u) & ~63u)) >> 6;
             const uint32_t NR = (nblk + ZZ_L6M_ROUND - 1u) / ZZ_L6M_ROUND;
             uint32_t vnext[2];                         // workers: the four bytes at their positions of the next round
-            auto fetch = [&](uint32_t t) {
+            auto fetch = [&](uint32_t t, uint32_t (&v)[2]) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t bi = t * ZZ_L6M_ROUND + 2u * (wave - ZZ_L6M_PLACERS) + (uint32_t)u;
                     const int32_t pos = g0 + (int32_t)(bi << 6) + lane;
-                    vnext[u] = load32(src + ((bi < nblk && pos >= lo && pos < hi) ? pos : lo));
+                    v[u] = load32(src + ((bi < nblk && pos >= lo && pos < hi) ? pos : lo));
                 }
             };
-            // the placer's round. FULL: every lane of every block has a position (all rounds but the first and the last)
-            auto place_round = [&](uint32_t r, auto fulltag) {
-                constexpr bool FULL = decltype(fulltag)::value;
-                const uint32_t r0 = r * ZZ_L6M_ROUND;
-                const uint32_t cnt = nblk - r0 < ZZ_L6M_ROUND ? nblk - r0 : ZZ_L6M_ROUND;
+            // the placer's round: thirty returning adds, thirty stores of what they returned -- nothing else
+            auto place_round = [&](uint32_t r) {
                 uint32_t* const slots = &ring[r & 1][0][0];
-                const uint32_t val0 = (uint32_t)(g0 + (int32_t)(r0 << 6) + lane + (int32_t)ZZ_L6_BIAS);
                 uint32_t inf[ZZ_L6M_ROUND], old[ZZ_L6M_ROUND];
 #pragma unroll
                 for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) inf[s] = slots[s * ZZ_WAVE + (uint32_t)lane];
 #pragma unroll
                 for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s)
-                    if (FULL || s < cnt) old[s] = atomicAdd((uint32_t*)((uint8_t*)Tw + (inf[s] & 0xFFFFu)), 1u << (inf[s] >> 16));
+                    old[s] = atomicAdd((uint32_t*)((uint8_t*)Tw + (inf[s] & 0xFFFFu)), 1u << (inf[s] >> 16));   // (a lane without a position: a counter of its own)
 #pragma unroll
-                for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) {
-                    if (FULL || s < cnt) {
-                        const uint32_t place = __builtin_amdgcn_ubfe(old[s], inf[s] >> 16, 16);
-                        if (FULL || (int32_t)inf[s] >= 0) {                        // (a lane without a position added to a counter of its own)
-                            sorted[ZZ_L6_PAD + place] = (uint16_t)(val0 + (s << 6));
-                            slots[s * ZZ_WAVE + (uint32_t)lane] = place;
-                        }
-                    }
-                }
+                for (uint32_t s = 0; s < ZZ_L6M_ROUND; ++s) slots[s * ZZ_WAVE + (uint32_t)lane] = old[s];
             };
-            if (wave >= ZZ_L6M_PLACERS) fetch(0);
-            else __builtin_amdgcn_s_setprio(3);        // the placers' streams of adds are the serial part of a packet
-            for (uint32_t t = 0; t <= NR + 1; ++t) {
+            if (wave >= ZZ_L6M_PLACERS) fetch(0, vnext);
+            else __builtin_amdgcn_s_setprio(3);        // the placer's stream of adds is the serial part of a packet
+            uint32_t inf1[2] = { 0x80000000u, 0x80000000u }, inf2[2] = { 0x80000000u, 0x80000000u };   // workers: what they sent the placer one / two rounds ago
+            uint32_t plc[2] = { 0, 0 };                                                                // ... and the places of their blocks of three rounds ago
+            for (uint32_t t = 0; t <= NR + 2; ++t) {
                 if (wave < ZZ_L6M_PLACERS) {
-                    if (t >= 1 && t <= NR) {
-                        if (t >= 2 && t * ZZ_L6M_ROUND < nblk) place_round(t - 1, std::true_type());
-                        else place_round(t - 1, std::false_type());
-                    }
+                    if (t >= 1 && t <= NR) place_round(t - 1);
                 } else {
                     const uint32_t s0 = 2u * (wave - ZZ_L6M_PLACERS);
-                    uint32_t place[2] = { 0, 0 };
-                    uint32_t mb[2] = { ~0u, ~0u };              // the packet block whose chains to copy (round t-2), ~0: none
+                    // round t-3: the chains of the packet's own positions (every earlier position stands in the array since the last barrier)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t bi = (t - 3) * ZZ_L6M_ROUND + s0 + (uint32_t)u;
+                        if (t >= 3 && bi < nblk && bi >= (Wr >> 6)) {
+                            const uint32_t q = ((bi - (Wr >> 6)) << 6) + (uint32_t)lane;
+                            if (q < target) {
+                                uint16_t c[DEPTH];
+#pragma unroll
+                                for (int i = 0; i < DEPTH; ++i) c[i] = sorted[ZZ_L6_PAD + plc[u] - DEPTH + i];     // nearest last
+                                __builtin_memcpy(chains + (uint64_t)q * DEPTH, c, 2 * DEPTH);
+                            }
+                        }
+                    }
+                    // round t-2: what the placer's adds returned is the place; the position goes into the array
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const uint32_t bi = (t - 2) * ZZ_L6M_ROUND + s0 + (uint32_t)u;
-                        if (t >= 2 && bi < nblk && bi >= (Wr >> 6)) { mb[u] = bi - (Wr >> 6); place[u] = ring[t & 1][s0 + u][lane]; }
+                        if (t >= 2 && bi < nblk) {
+                            const uint32_t old = ring[t & 1][s0 + u][lane];
+                            plc[u] = __builtin_amdgcn_ubfe(old, inf2[u] >> 16, 16);
+                            if ((int32_t)inf2[u] >= 0) sorted[ZZ_L6_PAD + plc[u]] = (uint16_t)(g0 + (int32_t)(bi << 6) + lane + (int32_t)ZZ_L6_BIAS);
+                        }
                     }
                     ZZ_WAVE_SYNC();
+                    // round t: the hashes, as the placer wants them: byte address of the counter's word | shift << 16
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { inf2[u] = inf1[u]; inf1[u] = 0x80000000u | (ZZ_HASH_SIZE * 2u); }
                     if (t < NR) {
-                        // the next round's hashes, as the placer wants them: byte address of the counter's word | shift << 16
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const uint32_t bi = t * ZZ_L6M_ROUND + s0 + (uint32_t)u;
                             const int32_t pos = g0 + (int32_t)(bi << 6) + lane;
                             const bool act = bi < nblk && pos >= lo && pos < hi;
                             const uint32_t h = l6_hash4(vnext[u]);
-                            ring[t & 1][s0 + u][lane] = act ? (((h >> 1) << 2) | ((h & 1u) << 20)) : (0x80000000u | (ZZ_HASH_SIZE * 2u));
+                            if (act) inf1[u] = ((h >> 1) << 2) | ((h & 1u) << 20);
+                            ring[t & 1][s0 + u][lane] = inf1[u];
                         }
-                        fetch(t + 1);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (mb[u] != ~0u) {
-                            const uint32_t q = (mb[u] << 6) + (uint32_t)lane;
-                            if (q < target) {
-                                uint16_t c[DEPTH];
-#pragma unroll
-                                for (int i = 0; i < DEPTH; ++i) c[i] = sorted[ZZ_L6_PAD + place[u] - DEPTH + i];     // nearest last
-                                __builtin_memcpy(chains + (uint64_t)q * DEPTH, c, 2 * DEPTH);
-                            }
-                        }
+                        fetch(t + 1, vnext);
                     }
                 }
                 __syncthreads();
-                if (t * ZZ_L6M_ROUND < (Wr >> 6) + 2 * ZZ_L6M_ROUND) { ZZ_T(9); } else { ZZ_T(12); }   // rounds without / with chain copies
+                if (t * ZZ_L6M_ROUND < (Wr >> 6) + 3 * ZZ_L6M_ROUND) { ZZ_T(9); } else { ZZ_T(12); }   // rounds without / with chain copies
             }
             if (wave < ZZ_L6M_PLACERS) __builtin_amdgcn_s_setprio(0);
             // ---- 3: the window and the packet into LDS (position p at byte 32768 + p: an array entry IS its position's offset) ----
