@@ -122,7 +122,7 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
     __shared__ __attribute__((aligned(16))) uint32_t Tw[ZZ_HASH_SIZE / 2 + 4];      // 8192 16-bit counters, two per word (+ the one lanes without a position use)
     __shared__ __attribute__((aligned(16))) uint32_t ring[2][ZZ_L6M_ROUND][ZZ_WAVE];
     __shared__ uint32_t wtot[ZZ_L6M_THREADS / ZZ_WAVE];
-    __shared__ uint32_t nextk;
+    __shared__ uint32_t nextk, nextblk;
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
     const uint32_t wave = uniform(tid >> 6);
@@ -228,9 +228,10 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
                         if (t >= 3 && bi < nblk && bi >= (Wr >> 6)) {
                             const uint32_t q = ((bi - (Wr >> 6)) << 6) + (uint32_t)lane;
                             if (q < target) {
-                                uint16_t c[DEPTH];
-#pragma unroll
-                                for (int i = 0; i < DEPTH; ++i) c[i] = sorted[ZZ_L6_PAD + plc[u] - DEPTH + i];     // nearest last
+                                // (entries plc - DEPTH .. plc - 1, nearest last: 2*DEPTH bytes at two-byte alignment -- read as aligned
+                                // words and shifted; a 16-byte LDS read off its alignment is replayed at 64 cycles)
+                                uint64_t c[2];
+                                lds_gather16((zz_lds_bytes)(const uint8_t*)sorted, 2u * (ZZ_L6_PAD + plc[u] - DEPTH), c[0], c[1]);
                                 __builtin_memcpy(chains + (uint64_t)q * DEPTH, c, 2 * DEPTH);
                             }
                         }
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
                     *(uint4*)(L + ((uint32_t)c << 4)) = v;
                 }
             }
+            if (tid == 0) nextblk = ZZ_L6M_THREADS / ZZ_WAVE;      // the blocks of the compare step beyond every wavefront's first
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the chains: no stale line of the previous packet's in the L1
             ZZ_T(15);
@@ -297,13 +299,21 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
                     __builtin_memcpy(ch.c, chains + (uint64_t)(q < target ? q : 0u) * DEPTH, 2 * DEPTH);
                     return ch;
                 };
-                chain_t nextc = ldchain(wave);                                  // (one block's chains ahead of their use)
-                for (uint32_t b = wave; b < npb; b += ZZ_L6M_THREADS / ZZ_WAVE) {
+                // blocks come from a counter (their costs differ with the data: with a fixed share per wavefront the slowest one took
+                // half as long again as the fastest), and a block's chains are requested one block ahead of their use
+                auto grab = [&]() -> uint32_t {
+                    uint32_t v = 0;
+                    if (lane == 0) v = atomicAdd(&nextblk, 1u);
+                    return uniform(v);
+                };
+                uint32_t b = wave, bn = b < npb ? grab() : npb;
+                chain_t nextc = ldchain(b < npb ? b : 0u);
+                for (; b < npb; b = bn, bn = bn < npb ? grab() : npb) {
                     const uint32_t q = (b << 6) + (uint32_t)lane;
                     const bool act = q < target;
                     const uint32_t qa = act ? q : 0u;
                     const chain_t cur = nextc;
-                    nextc = ldchain(b + ZZ_L6M_THREADS / ZZ_WAVE < npb ? b + ZZ_L6M_THREADS / ZZ_WAVE : b);
+                    nextc = ldchain(bn < npb ? bn : b);
                     const uint16_t* c = cur.c;
                     uint64_t w, w2;
                     lds_gather16(L, ZZ_L6_BIAS + qa, w, w2);                        // q + 16 <= n: inside the data
