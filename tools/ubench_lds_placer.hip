@@ -59,6 +59,11 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, uint32_t seed
                 for (int s = 0; s < 30; ++s) { const uint64_t* p = (const uint64_t*)((const uint8_t*)sorted + a[s] * 8); const uint64_t u = p[0]; o[s] = (uint32_t)(u ^ (u >> 37)); }
 #pragma unroll
                 for (int s = 0; s < 30; ++s) sink += o[s];
+            } else if (KIND == 9) {            // sixteen bytes at a random 16-aligned offset (ds_read_b128)
+#pragma unroll
+                for (int s = 0; s < 30; ++s) { const uint4 u = *(const uint4*)((const uint8_t*)sorted + a[s] * 16); o[s] = u.x ^ u.y ^ u.z ^ u.w; }
+#pragma unroll
+                for (int s = 0; s < 30; ++s) sink += o[s];
             } else {                           // one 4-byte word at a random 4-aligned offset
 #pragma unroll
                 for (int s = 0; s < 30; ++s) o[s] = ((const uint32_t*)sorted)[a[s] * 2 + (lane & 1)];
@@ -94,6 +99,6 @@ int main()
     run<3, false>("ds_write_b32 lane-contiguous"); run<3, true>("ds_write_b32 lane-contiguous");
     run<4, false>("ds_read_b32 lane-contiguous"); run<4, true>("ds_read_b32 lane-contiguous");
     run<5, false>("ds_read_u16 scattered"); run<5, true>("ds_read_u16 scattered");
-    run<6, false>("ds_read2_b64 scattered, 8-aligned"); run<7, false>("ds_read_b64 scattered, 8-aligned"); run<8, false>("ds_read_b32 scattered");
+    run<6, false>("ds_read2_b64 scattered, 8-aligned"); run<7, false>("ds_read_b64 scattered, 8-aligned"); run<8, false>("ds_read_b32 scattered"); run<9, false>("ds_read_b128 scattered, 16-aligned");
     return 0;
 }
