@@ -665,6 +665,31 @@ def test_warm_window_through_the_host_entry_points(gpu, oracle, corpus):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_extended_levels_in_batches(gpu, oracle, corpus):
+    """The extended levels go through a call in batches of packets (k_l6_matches over a batch, then the encode kernel over the
+    same packets; 1 GiB of input per batch by default: only the 8 GiB shard test gets there). With ZZFLATE_L6_BATCH_MIB=1 a few
+    MiB make several batches -- with packets of 32768 and 4096 bytes, a last batch that is not full, one workgroup per packet
+    and fewer -- and the stream must not change. In a child process: the variable is read once."""
+    import subprocess, sys
+    code = (
+        "import os, sys, zlib; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import torch\nimport zzflate_amd as zz\nfrom conftest import Oracle, CORPUS\n"
+        "d = b''.join(open(os.path.join(CORPUS, f), 'rb').read() for f in ('lcet10.txt', 'kennedy.xls', 'ptt5', 'plrabn12.txt')) * 2 + b'tail'\n"
+        "ctx = zz.Context(0); ctx.set_extended_levels(True); o = Oracle()\n"
+        "src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()\n"
+        "for lvl, P in ((6, 32768), (4, 4096), (5, 32768)):\n"
+        "    cap = zz.bound(len(d), 0, 2, P); dst = torch.zeros(cap, dtype=torch.uint8, device='cuda')\n"
+        "    w = ctx.encode(src, len(d), dst, cap, 0, lvl, P)\n"
+        "    assert ctx.verify_last() == (0, None)\n"
+        "    got = dst[:w].cpu().numpy().tobytes()\n"
+        "    assert got == o.encode_packets(d, 0, lvl, P), (lvl, P, len(got))\n"
+        "    assert zlib.decompress(got) == d\n"
+        "print('ok', len(d))\n") % (ROOT_DIR, ROOT_DIR)
+    env = dict(os.environ, ZZFLATE_L6_BATCH_MIB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("lvl", LEVELS)
 def test_shards_concatenate_to_the_whole_stream(gpu, oracle, corpus, lvl):
     """Multi-GPU contract on one GPU: shards cut at packet boundaries + checksum combine == one call."""
