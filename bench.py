@@ -582,7 +582,8 @@ def main():
             "calls_in_flight": len(lanes) if (not multi) else None,
             "exchange": exchange if multi else None,
             "roofline": {
-                "bound": "hbm", "kernel": "k_encode_l2_t" if args.level >= 2 else f"k_encode_l{args.level}",
+                "bound": "hbm", "kernel": ("k_l6_matches + k_encode_l2_t" if args.level >= 4 else "k_encode_l2_t" if args.level >= 2
+                                           else f"k_encode_l{args.level}"),
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4), "traffic": traffic,
