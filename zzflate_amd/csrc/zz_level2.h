@@ -1017,15 +1017,21 @@ struct zz_l2_params {
 // BIAS = 32768: the same with a warm window (P.warm bytes in front of every packet are hashed into its table first).
 // XD: the extended levels 4..6 (zz_level6.h) -- the parser walks the per-position matches that k_l6_matches left in Q.m instead
 // of probing a table, and the code lengths come from package-merge; everything else is shared.
+// XD needs no hash table: what sits behind it in LDS moves down to where the code-construction scratch and the helper's bit ring
+// end, 13,760 bytes in all => eleven workgroups per CU instead of nine (22 wavefronts: six on two of the SIMDs => at most 80
+// VGPRs): the encode kernel of level 6 12.1 -> 10.0 ms per GiB. (Twelve -- the helper's ring over the dead match-start bits
+// and counters, 12,992 bytes -- ran no faster: 26.4 against 26.3 ms.)
 template <uint32_t BIAS, bool XD = false>
-__global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q)
+__global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2_params Q)
 {
     const zz_packet_params& P = Q.pk;
     // ---- LDS carve-up: 17,840 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
     // The hash table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the
     // code tables all live inside it; the bit ring (used after the token pass) shares its space with the
     // hand-over slots (used during it); the bitmap window and the packed counters have their own.
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ZZ_L2_LDS_BYTES + 16];
+    constexpr uint32_t HB = XD ? 12288u : 16384u;                 // where the part behind the hash table starts (XD: behind the helper's bit ring at 11520)
+    constexpr uint32_t RING2 = 11520u;                            // the helper's bit ring of the emission
+    __shared__ __attribute__((aligned(16))) uint8_t lds[HB + (ZZ_L2_LDS_BYTES - 16384) + 16];
     uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table during the token pass
     uint32_t* symF = (uint32_t*)(lds + 8192);                     // 1280: 286 lit/len + pad | 30 dist at [288..318)
     uint32_t* distF = symF + 288;
@@ -1033,11 +1039,11 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
     uint32_t* dcodes = (uint32_t*)(lds + 8192 + 1280 + 1152);     // 128: 30 distance codes
     uint32_t* metaF = (uint32_t*)(lds + 8192 + 1280 + 1152 + 128);            // 80: 19 meta frequencies
     uint32_t* misc = (uint32_t*)(lds + 11264);                    // 256: lane-0 results [0..3], code-generation work area [16..48)
-    uint32_t* ring_words = (uint32_t*)(lds + 16384);              // 512 (+48 pad)
-    uint32_t* hb = (uint32_t*)(lds + 16384);                      // 560: two hand-over slots, same bytes as the ring
-    uint64_t* covw = (uint64_t*)(lds + 16384 + 560);              // 128: covered bits of the 16 blocks around the probe front
+    uint32_t* ring_words = (uint32_t*)(lds + HB);                 // 512 (+48 pad)
+    uint32_t* hb = (uint32_t*)(lds + HB);                         // 560: two hand-over slots, same bytes as the ring
+    uint64_t* covw = (uint64_t*)(lds + HB + 560);                 // 128: covered bits of the 16 blocks around the probe front
     uint64_t* mstw = covw + ZZ_L2_WIN;                            // 128: match-start bits
-    uint32_t* histP = (uint32_t*)(lds + 16384 + 560 + 2 * ZZ_L2_WIN * 8);     // 640: packed 16-bit counters
+    uint32_t* histP = (uint32_t*)(lds + HB + 560 + 2 * ZZ_L2_WIN * 8);        // 640: packed 16-bit counters
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -1154,7 +1160,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
                     uint32_t m1 = 0;
                     const uint32_t bits1 = l2_count_bits(recs, tokens, codes, dcodes, r1, m1);
                     bitring ring2;
-                    ring_init_at(ring2, (uint32_t*)(lds + 11520), out, uniform(share[2]) + bits1, share + 4);
+                    ring_init_at(ring2, (uint32_t*)(lds + RING2), out, uniform(share[2]) + bits1, share + 4);
                     l2_emit_records(ring2, recs, tokens, codes, dcodes, r1, nbody, m1);
                     {   // codes[256] (:300)
                         const uint32_t cd = codes[256];
@@ -1318,9 +1324,9 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, 5) void k_encode_l2_t(zz_l2_params Q
 }
 
 // xdepth: 0 = levels 2,3; 2 / 4 / 8 = the extended levels 4 / 5 / 6 (chain depth)
-static inline uint32_t l2_grid(uint32_t npk)
+static inline uint32_t l2_grid(uint32_t npk, bool xd = false)
 {
-    const uint32_t resident = 256 * 9;     // what the LDS budget admits
+    const uint32_t resident = 256 * (xd ? 11 : 9);     // what the LDS budget admits
     return npk < resident ? npk : resident;
 }
 // the extended levels go through the input in batches of about 1 GiB: k_l6_matches over a batch's packets (one word per input
@@ -1339,7 +1345,7 @@ static inline uint32_t l6_match_grid()      // one workgroup per CU: it takes th
 static inline uint64_t l6_m_bytes(uint32_t npk, uint32_t P) { return ((uint64_t)l6_batch_packets(npk, P) * P * 4u + 255u) & ~255ull; }
 static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth, uint32_t P)
 {
-    uint64_t need = (uint64_t)l2_grid(npk) * ZZ_L2_SCRATCH_BYTES;
+    uint64_t need = (uint64_t)l2_grid(npk, xdepth != 0) * ZZ_L2_SCRATCH_BYTES;
     if (xdepth) need += l6_m_bytes(npk, P) + (uint64_t)l6_match_grid() * 32768u * 2u * (uint32_t)xdepth;   // + the chains of every resident packet
     return need;
 }
@@ -1353,7 +1359,7 @@ static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, u
         else hipLaunchKernelGGL((k_encode_l2_t<0u, false>), g, b, 0, st, q);
         return;
     }
-    uint32_t* const m = (uint32_t*)(scratch + (uint64_t)l2_grid(pp.npk) * ZZ_L2_SCRATCH_BYTES);
+    uint32_t* const m = (uint32_t*)(scratch + (uint64_t)l2_grid(pp.npk, true) * ZZ_L2_SCRATCH_BYTES);
     const uint32_t batch = l6_batch_packets(pp.npk, pp.packet_size);
     const uint32_t mgrid = l6_match_grid();
     uint16_t* const chains = (uint16_t*)((uint8_t*)m + l6_m_bytes(pp.npk, pp.packet_size));
@@ -1366,7 +1372,7 @@ static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, u
         else if (xdepth == 4) hipLaunchKernelGGL((k_l6_matches<4>), gm, bm, 0, st, qm);
         else hipLaunchKernelGGL((k_l6_matches<8>), gm, bm, 0, st, qm);
         q.m = m; q.k0 = k0; q.k1 = k1;
-        const dim3 g(l2_grid(k1 - k0)), b(ZZ_L2_THREADS);
+        const dim3 g(l2_grid(k1 - k0, true)), b(ZZ_L2_THREADS);
         hipLaunchKernelGGL((k_encode_l2_t<32768u, true>), g, b, 0, st, q);
     }
 }
