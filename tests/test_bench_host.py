@@ -53,3 +53,17 @@ def test_native_timing_drivers_do_the_work_they_time(oracle):
             assert produced == want_packets, (name, threads)
             wall, produced, secs = _drive(lib, name, sample, 0, threads, 1)
             assert all(0 < p < (1 << 20) for p in produced)      # text compresses; one whole-slice stream per slice
+
+
+def test_profile_summaries_keep_template_instantiations_apart():
+    """tools/summarize_pmc.py: `k_encode_l2_t<0u, false>` (level 2) and `k_encode_l2_t<32768u, true>` (the extended levels'
+    encode kernel) are different kernels in profiles/traffic.json; return type and parameter list go, template arguments stay."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("summarize_pmc", os.path.join(ROOT, "tools", "summarize_pmc.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.short('"void zz::k_encode_l2_t<0u, false>(zz::zz_l2_params)"') == "zz::k_encode_l2_t<0u, false>"
+    assert m.short('"void zz::k_encode_l2_t<32768u, true>(zz::zz_l2_params)"') == "zz::k_encode_l2_t<32768u, true>"
+    assert m.short('"zz::k_encode_l1(zz_packet_params)"') == "zz::k_encode_l1"
+    assert m.short('"void zz::k_l6_matches<8>(zz::zz_l6m_params)"') == "zz::k_l6_matches<8>"
+    assert m.short("k_generate(int, unsigned long, unsigned long, unsigned char*, unsigned long)") == "k_generate"
