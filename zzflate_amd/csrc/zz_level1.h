@@ -346,6 +346,9 @@ __device__ __forceinline__ void l1_emit_tokens(bitring& ring, const uint32_t* lc
     ring_append(ring, bits, nb);
 }
 
+#ifdef ZZ_L1_PIPE_PROBE
+__device__ __forceinline__ uint32_t l1_probe_blocks(uint32_t n) { return n < 6 * ZZ_WAVE ? 0u : ((n - 4 * ZZ_WAVE) / ZZ_WAVE) & ~1u; }
+#endif
 // TT = uint16_t: packet mode, positions < 32768, every candidate is within reach.
 // TT = uint32_t: the sequential whole-buffer stream (threaded=false, one block for the whole input): positions up
 //      to 2^32, candidates further than 32768 back are ignored (encoder.cpp:348) but stay in the table.
@@ -372,11 +375,18 @@ __device__ __forceinline__ void l1_group_barrier()
 template <bool SAFE, typename TT, bool SPLIT = false, uint32_t BIAS = 0>
 __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T, const uint32_t* lcodes,
                                                bitring& ring, const uint8_t* src, const uint8_t* end, uint32_t n,
-                                               uint32_t* tokbuf = nullptr, uint32_t start = 0)
+                                               uint32_t* tokbuf = nullptr, uint32_t start = 0, uint32_t pw = 0)
 {
     const int lane = lane_id();
     const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
     ZZ_PROF_DECL
+    (void)pw;
+#ifdef ZZ_L1_PIPE_PROBE
+    // TIMING PROBE ONLY (tools/pipe_probe.sh; the output is NOT a valid stream): two parsing wavefronts per packet take
+    // alternate blocks of 64 positions, block g + 1 probed and compared while block g is walked -- the optimistic bound of a
+    // two-stage pipeline over one packet: no cross-block same-hash resolution, no exchange, no carried match end.
+    start += ZZ_WAVE * pw;
+#endif
     uint32_t cur = start;
     uint32_t ptok = 0;                                                    // previous group's tokens
     // Packet mode (SPLIT): lanes past the block's end take part in the table accesses and loads like everyone else --
@@ -422,8 +432,12 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // time (phase stamps); where it does not, the load happens as before.
         uint64_t sA = 0, sA2 = 0, sB = 0, sB2 = 0;
         if (INTERIOR) {
+#ifdef ZZ_L1_PIPE_PROBE
+            ld128<SAFE>(src + cur + 2 * ZZ_WAVE + lane, end, sA, sA2);
+#else
             ld128<SAFE>(src + cur + ZZ_WAVE + lane, end, sA, sA2);
             ld128<SAFE>(src + cur + ZZ_WAVE + 16 + lane, end, sB, sB2);
+#endif
         }
         ZZ_WAVE_SYNC();
         uint32_t rb = 0;
@@ -469,7 +483,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         // second half of the previous group's hand-over. The barrier sits behind the wait for the candidate bytes (the operand
         // ties it there): the emitter is released where this wave has just been waiting anyway, +0.4 % over a barrier at the
         // top of the group (profiles/README.md, round 3)
+#ifndef ZZ_L1_PIPE_PROBE
         if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :: "v"((uint32_t)x) : "memory");
+#endif
         uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
         if (!old) la = 0;
         info |= la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la;
@@ -499,6 +515,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         uint32_t& ovlen = X.ovlen; uint32_t& ovcand1 = X.ovcand1;
         uint64_t& ovmL = X.ovmL; uint64_t& ovmC = X.ovmC;
         uint32_t pos = 0;
+#ifdef ZZ_L1_PIPE_PROBE
+        if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :: "v"(info) : "memory");     // the block in front has been walked
+#endif
         l1_fast_walk<true>(E, info, nact, pos, mst, cov, usedB, X);
         while (pos < nact) {
             const int e = (int)pos;                                     // the walk stopped AT an event it cannot decide
@@ -553,6 +572,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB, X);
         }
         ZZ_T(6);
+#ifdef ZZ_L1_PIPE_PROBE
+        if (SPLIT) asm volatile("s_barrier" :: "s"(pos) : "memory");                                   // this block has been walked
+#endif
         // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
         // (the walk leaves 1 <= pos, and pos <= nact wherever nact < 64: every lane below pos is an active one)
         uint64_t committed;
@@ -563,10 +585,17 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         } else {
             committed = (~cov & (~0ull >> (64u - (pos < 64u ? pos : 64u)))) | mst;
         }
+#ifdef ZZ_L1_PIPE_PROBE
+        const uint32_t next = SPLIT ? cur + 2 * ZZ_WAVE : cur + pos;
+#else
         const uint32_t next = cur + pos;
+#endif
         // next group's bytes: in flight while this group is repaired
         uint64_t wnext = 0, wnext2 = 0;
         if (MASKED) { if (next + (uint32_t)lane < n) ld128<SAFE>(src + next + lane, end, wnext, wnext2); }
+#ifdef ZZ_L1_PIPE_PROBE
+        else if (INTERIOR) { wnext = sA; wnext2 = sA2; }
+#endif
         else if (INTERIOR && pos <= ZZ_WAVE + 16) {
             // the guess held: bytes d .. d+15 of the 32 requested at the top of the group (d = pos - 64, uniform)
             const uint32_t d = pos - ZZ_WAVE, sh = d & 3u;
@@ -661,7 +690,9 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
             // hand-over, first half: the tokens go to the slot now; the barrier that releases them to the emitter
             // sits in the next trip, behind the wait for the table read that trip needs anyway
             *slot = ptok;
+#ifndef ZZ_L1_PIPE_PROBE
             slot = lds_flip_slot(slot);
+#endif
         }
         if (sizeof(TT) == 4 && ring.flushed >= (1u << 24)) {
             // long streams: slide the ring's origin (by a multiple of the ring size, so slots keep their meaning)
@@ -675,6 +706,18 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
         ZZ_T(8);
     };
     // (lane 63 has 17 bytes left, and the 32 bytes requested for the next group lie inside the block: cur + 64 + 63 + 32 <= n)
+#ifdef ZZ_L1_PIPE_PROBE
+    if (SPLIT) {
+        // the same number of barriers in every wavefront of the workgroup: nb blocks (even), two barriers per block and one
+        // of offset: parser 1 starts a barrier late, parser 0 ends a barrier late; the rest of the packet is dropped
+        const uint32_t nb = l1_probe_blocks(n);
+        slot = (lds_u32*)tokbuf + lane + pw * ZZ_L1_TOKSLOT;
+        if (pw == 1) asm volatile("s_barrier" ::: "memory");
+        for (uint32_t b = pw; b < nb; b += 2) group(std::true_type{});
+        if (pw == 0) asm volatile("s_barrier" ::: "memory");
+        return;
+    }
+#endif
     if (SPLIT) while (cur + 2 * ZZ_WAVE + 32 <= n) group(std::true_type{});
     const bool flagged = cur < n;                                       // the last group will carry ZZ_TOK_LAST
     while (cur < n) group(std::false_type{});
@@ -692,9 +735,19 @@ __device__ __forceinline__ void l1_encode_body(const zz_packet_params& P, TT* T,
 // The other half of SPLIT: Huffman-codes and appends group after group (fixed codes computed, no table in LDS).
 // It reads slot g & 1 into registers right after barrier g; the parser overwrites that slot only after barrier
 // g + 1, which this wave reaches after the read.
-__device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf)
+__device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf, uint32_t n = 0)
 {
     const lds_u32* slot = (const lds_u32*)tokbuf + lane_id();
+    (void)n;
+#ifdef ZZ_L1_PIPE_PROBE
+    for (uint32_t b = 0, nb = l1_probe_blocks(n) + 1; b < nb; ++b) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const uint32_t tok = *slot;
+        slot = lds_flip_slot((lds_u32*)slot);
+        l1_emit_tokens(ring, nullptr, tok & ~ZZ_TOK_LAST);
+    }
+    return;
+#endif
     l1_group_barrier();                                                  // the parser's barrier in front of its first group
     for (;;) {
         l1_group_barrier();
@@ -708,7 +761,11 @@ __device__ __forceinline__ void l1_emitter(bitring& ring, const uint32_t* tokbuf
 // Two wavefronts per packet: wave 0 parses (hash table, match search, the serial walk), wave 1 computes the Adler-32
 // and turns the parser's tokens into the bit stream; they meet at one s_barrier per group of 64 positions (see
 // l1_encode_body). Both execute exactly one barrier per group, so the counts always match.
+#ifdef ZZ_L1_PIPE_PROBE
+#define ZZ_L1_THREADS (3 * ZZ_WAVE)
+#else
 #define ZZ_L1_THREADS (2 * ZZ_WAVE)
+#endif
 // what a packet is, for both wavefronts
 struct l1_pk {
     const uint8_t* src; const uint8_t* end; uint8_t* out;
@@ -791,7 +848,7 @@ __device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, in
 }
 
 template <uint32_t BIAS>
-__device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf)
+__device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf, uint32_t pw = 0)
 {
     const int lane = lane_id();
     const l1_pk q = l1_packet_of(P, k);
@@ -801,6 +858,7 @@ __device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint
     uint4* t4 = (uint4*)T;
     for (int i = lane; i < (int)(ZZ_HASH_SIZE * sizeof(uint16_t) / 16); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
     ZZ_WAVE_SYNC();
+    (void)pw;
     if (BIAS) {
         const uint64_t before = P.halo + q.off;                       // input bytes of this stream in front of the packet
         // key of a position: bytes pos+1..pos+3 (encoder.cpp:344); spare slot: the last half word of the hand-over slots, unused so far
@@ -811,8 +869,8 @@ __device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint
     if (q.n > 0) {
         // 16-byte loads may run up to 15 bytes past the packet's last byte: bounds-checked loads wherever that
         // would leave the shard (decided by bytes, not by packet index: packets may be as short as one byte)
-        if (q.off + q.len + 16 > P.n) l1_encode_body<true, uint16_t, true, BIAS>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf);
-        else l1_encode_body<false, uint16_t, true, BIAS>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf);
+        if (q.off + q.len + 16 > P.n) l1_encode_body<true, uint16_t, true, BIAS>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf, 0, pw);
+        else l1_encode_body<false, uint16_t, true, BIAS>(P, T, nullptr, none, q.src, q.end, q.n, tokbuf, 0, pw);
     }
 }
 // ---- emitter ---------------------------------------------------------------------------------------------------------
@@ -832,7 +890,7 @@ __device__ __forceinline__ void l1_packet_emitter(const zz_packet_params& P, uin
     if (q.n > 0) {
         // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
         ring_append_uniform(ring, (q.is_final ? 1u : 0u) | (1u << 1), 3);
-        l1_emitter(ring, tokbuf);
+        l1_emitter(ring, tokbuf, q.n);
         // EOB: codes_f[256] = 7 zero bits (encoder.cpp:371)
         ring_append_uniform(ring, 0, 7);
     }
@@ -867,6 +925,11 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1(zz_packet_params P)
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
     __shared__ __attribute__((aligned(512))) uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
     const uint32_t k = blockIdx.x;
+#ifdef ZZ_L1_PIPE_PROBE
+    if (uniform(threadIdx.x >> 6) < 2) l1_packet_parser<0>(P, k, T, tokbuf, uniform(threadIdx.x >> 6));
+    else l1_packet_emitter(P, k, ring_words, tokbuf);
+    return;
+#endif
     if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<0>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
 }
@@ -877,6 +940,9 @@ __global__ __launch_bounds__(ZZ_L1_THREADS) void k_encode_l1w(zz_packet_params P
     __shared__ uint32_t ring_words[ZZ_RING_WORDS];
     __shared__ __attribute__((aligned(512))) uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
     const uint32_t k = blockIdx.x;
+#ifdef ZZ_L1_PIPE_PROBE
+    return;                                        // (the probe build has three wavefronts per workgroup: cold packets only)
+#endif
     if (uniform(threadIdx.x >> 6) == 0) l1_packet_parser<32768u>(P, k, T, tokbuf);
     else l1_packet_emitter(P, k, ring_words, tokbuf);
 }
