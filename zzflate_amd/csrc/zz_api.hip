@@ -21,6 +21,7 @@
 #include "zz_emit.h"
 #include "zz_level0.h"
 #include "zz_level1.h"
+#include "zz_level1p.h"
 #include "zz_level2.h"
 #include "zz_stream2.h"
 #include "zz_compact.h"
@@ -52,6 +53,7 @@ struct zz_ctx {
     zz_result* d_res = nullptr; zz_cks_total* d_cks_total = nullptr; uint32_t* d_err = nullptr;
     zz_result* h_res = nullptr;          // pinned
     unsigned long long* d_prof = nullptr; // 16 counters for diagnostic (-DZZ_PROF) builds
+    uint8_t* d_tail = nullptr;            // 128 bytes: the end of the shard being encoded, then zeros (k_encode_l1p's over-reads)
     // staging for the host-buffer entry points
     uint8_t* stage_in = nullptr;  uint64_t stage_in_cap = 0;
     uint8_t* stage_out = nullptr; uint64_t stage_out_cap = 0;
@@ -80,6 +82,13 @@ struct zz_ctx {
 // Small host values (an empty input's block, a result record whose size is known up front) reach the device as kernel
 // ARGUMENTS -- copied at launch -- not as asynchronous copies from stack locals, which would still be read after an
 // enqueue-only call (zz_encode_device_async) has returned.
+// the last min(n, 64) bytes of a shard, then zeros: what k_encode_l1p reads instead of bytes past the shard's end
+__global__ void k_fill_tail(const uint8_t* src, uint64_t n, uint8_t* tail)
+{
+    const uint64_t tn = n < 64 ? n : 64;
+    const uint32_t i = threadIdx.x;
+    tail[i] = i < tn ? src[n - tn + i] : (uint8_t)0;
+}
 __global__ void k_put_small(uint8_t* dst, uint64_t bytes, uint32_t nbytes, zz_result* res, uint64_t stream_bytes)
 {
     for (uint32_t i = 0; i < nbytes; ++i) dst[i] = (uint8_t)(bytes >> (8 * i));
@@ -132,6 +141,7 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)));          // [0] slot overflow, [1] stream truncated, [2] log entries
         HIPCHK(hipMalloc(&c->d_work, 16 * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&c->d_tail, 128));
         HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&c->h_err, 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -151,7 +161,7 @@ extern "C" void zz_ctx_destroy(zz_ctx* c)
     if (c->pend.active) { (void)hipStreamSynchronize(c->pend.st); c->pend.active = false; }   // an enqueued call still uses the buffers
     (void)hipFree(c->slots); (void)hipFree(c->sizes); (void)hipFree(c->offsets); (void)hipFree(c->cks);
     (void)hipFree(c->l2_scratch);
-    (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof);
+    (void)hipFree(c->d_res); (void)hipFree(c->d_cks_total); (void)hipFree(c->d_err); (void)hipFree(c->d_prof); (void)hipFree(c->d_tail);
     (void)hipFree(c->stage_in); (void)hipFree(c->stage_out); (void)hipFree(c->d_verify); (void)hipFree(c->d_work); (void)hipFree(c->d_log);
     for (int i = 0; i < 2; ++i) {
         (void)hipHostFree(c->pin_in[i]); (void)hipHostFree(c->pin_out[i]); (void)hipFree(c->slab_out[i]); (void)hipFree(c->slab_in[i]);
@@ -176,7 +186,8 @@ extern "C" uint64_t zz_ctx_workspace_bytes(const zz_ctx* c)
 extern "C" int zz_debug_occupancy(int level)
 {
     int nb = -1;
-    if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
+    if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1p, ZZ_L1P_THREADS, 0);
+    else if (level == -1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
     else if (level >= 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<32768u, true>, ZZ_L2_THREADS, 0);
     else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, false>, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
@@ -410,7 +421,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         zz_packet_params pp;
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
         pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind; pp.warm = warm;
-        pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof;
+        pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof; pp.tail = c->d_tail;
 
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));   // the CRC-32 pass of the gzip container is part of the timed work
         if (cks_kind == ZZ_CKS_CRC) {
@@ -433,8 +444,15 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         } else if (level == 1) {
             // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+            // ZZFLATE_L1_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet (k_encode_l1) instead of the two of
+            // k_encode_l1p; the streams are the same
+            static const bool classic = [] { const char* e = getenv("ZZFLATE_L1_KERNEL"); return e && !strcmp(e, "classic"); }();
             if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
-            else hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            else if (classic) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            else {
+                hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);
+                hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
+            }
         } else {
             launch_level2(pp, c->l2_scratch, c->d_work, st, xdepth);
         }
@@ -560,7 +578,7 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
     HIPCHK(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), st));
     zz_packet_params pp;
     memset(&pp, 0, sizeof pp);
-    pp.src = d_src; pp.n = n; pp.halo = 0; pp.last_is_final = 1; pp.err = c->d_err; pp.prof = c->d_prof;
+    pp.src = d_src; pp.n = n; pp.halo = 0; pp.last_is_final = 1; pp.err = c->d_err; pp.prof = c->d_prof; pp.tail = c->d_tail;
     std::vector<uint64_t> log;           // (bytes stored, length asked for) per EnsureOutputLength call, chunked form
     uint32_t log_cap = 0;
     if (level == 0) {

@@ -36,6 +36,7 @@ struct zz_packet_params {
     uint32_t* err;            // out: sticky error word (slot overflow etc.)
     unsigned long long* prof; // diagnostic builds (-DZZ_PROF) only: per-phase cycle sums; ignored otherwise
     uint32_t warm;            // level 1: bytes in front of a packet hashed into its table before the parse (0: cold, the reference)
+    const uint8_t* tail;      // k_encode_l1p: 128 bytes, the shard's last min(n, 64) bytes followed by zeros (k_fill_tail)
 };
 
 // ---- the sequential stream's output buffers (outputbitstream.h:171-201) ------------------------------------------

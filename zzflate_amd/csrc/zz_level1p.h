@@ -1,0 +1,444 @@
+// zz_level1p.h -- level 1, packet mode: TWO parsing wavefronts per packet, pipelined over blocks of 64 positions.
+//
+// The same stream as k_encode_l1 (zz_level1.h), i.e. WriteBlockFixedHuff (encoder.cpp:329-373) over a packet
+// (zzflate.cpp:101-125), bit for bit. What changes is who does what when. In k_encode_l1 ONE wavefront runs a packet's
+// whole dependency chain: probe / compare (about 200 instructions per 64 positions), then the serial walk (about 100), then
+// repair and tokens, then the next group -- and only nine such chains fit a CU (the 16 KiB table), which leaves the CU's
+// issue slots two-thirds empty (profiles/README.md, round 4: tools/ceiling_probe.sh, tools/pipe_probe.sh). Here the packet
+// is cut into fixed blocks of 64 positions and two wavefronts take alternate blocks:
+//
+//      wave A:  [probe 0] B0 [walk 0] B1 [repair 0, probe 2] B2 [walk 2] B3 [repair 2, probe 4] ...
+//      wave B:            B0 [probe 1] B1 [walk 1] B2 [repair 1, probe 3] B3 [walk 3] ...
+//
+// so that the only thing left on the packet's critical path is walk, hand-over, walk, hand-over. Block g + 1 is probed
+// while block g is still being walked, i.e. against a table that holds block g's SPECULATIVE entries (every position of
+// g entered; the walk has not said yet which of them the reference would have entered). That is resolved exactly:
+//   * a lane of g + 1 whose table read returns a position of block g ("cross lane", about a quarter of the lanes of text)
+//     has two possible candidates -- that position q if the walk of g visits it, else what the table held before block g
+//     under that hash (told_g[q], which block g's owner publishes as soon as it has resolved its own lanes) -- and
+//     compares against both before the walk of g has finished; the moment it has, one bit test per lane picks the
+//     right one (`R` below). If q is skipped but an earlier lane of g with the same hash is visited (rare: the chain of
+//     "nearest earlier lane with my hash" that g's owner publishes is followed), the lane is settled by the walk's
+//     out-of-line path with a load, like a lane whose hash occurs three times in its own block.
+//   * repair of block g (skipped lanes restore the old entry, the highest visited lane per hash wins: the state the
+//     serial loop leaves) runs after block g + 1 has entered its positions, so it only touches slots that still hold
+//     a position of block g; a slot block g + 1 has overwritten is that block's to repair, from its resolved old entry.
+//   * a match that runs past its block's end is carried: block g + 1's walk starts behind it (`cin`).
+// This relies on the LDS serving the lanes of one store that hit one address in ascending lane order (the slot ends up
+// with the HIGHEST position of the block under that hash): zz_ctx probes that once per device and falls back to
+// k_encode_l1 where it does not hold (zz_api.hip, lds_order_ok).
+//
+// Hand-over between the two parsers goes through 352 bytes of LDS (l1p_xch) and one s_barrier per block, which the
+// emitter wavefront (the third of the workgroup: Adler-32, fixed-Huffman coding, bit packing -- as in k_encode_l1) joins.
+// LDS: 16,384 table + 512 ring + 512 token slots + 352 = 17,760 bytes <= 17,920: nine workgroups per CU, 27 wavefronts.
+#pragma once
+#include "zz_level1.h"
+
+namespace zz {
+
+#define ZZ_L1P_THREADS (3 * ZZ_WAVE)
+// where the work that may sit on either side of a barrier sits (tools/sweep_define.sh): the two wavefronts alternate
+// between "walk" and "probe" intervals, and an interval lasts as long as the longer of the two
+#ifndef ZZ_L1P_PRIO_W
+#define ZZ_L1P_PRIO_W 3         // issue priority while a wavefront resolves and walks (the packet's critical path) ...
+#define ZZ_L1P_PRIO_F 1         // ... while it repairs and probes ...
+#define ZZ_L1P_PRIO_E 0         // ... and of the emitter
+#endif
+#ifndef ZZ_L1P_LEN_LATE
+#define ZZ_L1P_LEN_LATE 0       // 1: the lengths against the table's candidates behind the barrier, in the walk's interval
+#endif
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
+struct l1p_xch {
+    uint32_t told[ZZ_WAVE];        // per lane of block t - 1, t = the word's high half: the table's entry under the lane's hash BEFORE that block
+    uint8_t win[ZZ_WAVE];          // per lane of the block walked last: the highest VISITED lane of the block with the lane's hash, 0x80 = none
+    uint32_t scal[4];              // [0]: the positions by which the block walked last runs into the next one
+};   // 336 bytes
+
+
+// Loads that may run past the shard's last byte (only a shard's last packet has any, and only in its last blocks) are turned to
+// a 128-byte copy of the shard's end that the host keeps behind it: its last 64 bytes, then zeros (zz_packet_params::tail, filled
+// by k_fill_tail before the launch). One compare and one select per load, where bounds-checked byte-wise loads (load64_safe)
+// cost the kernel its register budget: 65 VGPRs and 100 SGPRs with them, 62 and 62 without.
+struct l1p_src {
+    const uint8_t* src;        // the packet's first byte
+    const uint8_t* tailp;      // tail copy, biased: tailp + position = the copy's byte for that position
+    int32_t lim;               // positions above this one (packet-relative) read from the copy: shard end - 16
+};
+template <bool TAIL> __device__ __forceinline__ const uint8_t* l1p_addr(const l1p_src& S, uint32_t pos)
+{
+    if (!TAIL) return S.src + pos;
+    return ((int32_t)pos > S.lim ? S.tailp : S.src) + pos;
+}
+template <bool TAIL> __device__ __forceinline__ void l1p_ld128(const l1p_src& S, uint32_t pos, uint64_t& lo, uint64_t& hi)
+{
+    uint4 v;
+    __builtin_memcpy(&v, l1p_addr<TAIL>(S, pos), 16);
+    lo = ((uint64_t)v.y << 32) | v.x;
+    hi = ((uint64_t)v.w << 32) | v.z;
+}
+// wave_extend_match (zz_level1.h) over these loads
+__device__ __forceinline__ uint32_t l1p_extend_match(const l1p_src& S, uint32_t pe, uint32_t cand, uint32_t maxlen, uint32_t from = 8)
+{
+    const uint32_t o = from + 4 * (uint32_t)lane_id();
+    uint32_t d = 0;
+    const bool act = o < maxlen;
+    if (act) d = load32(l1p_addr<true>(S, pe + o)) ^ load32(l1p_addr<true>(S, cand + o));
+    const uint64_t neq = ballot(act && d != 0);
+    if (!neq) return maxlen;
+    const int k = __builtin_ctzll(neq);
+    const uint32_t dk = readlane(d, k);
+    const uint32_t len = from + 4 * (uint32_t)k + ((uint32_t)__builtin_ctz(dk) >> 3);
+    return len < maxlen ? len : maxlen;
+}
+
+// One parsing wavefront (pw = 0: even blocks, 1: odd blocks). Barriers: B_g closes the walk of block g - 1. Per block g its
+// owner runs  [P1 P2](g)  B_g  [R W](g)  B_g+1  [P4](g)  and then block g + 2; the other wavefront is one barrier out of step.
+__device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk& pk, uint16_t* T, uint32_t* tokbuf, l1p_xch* X, const uint32_t pw)
+{
+    const int lane = lane_id();
+    const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
+    const uint32_t n = pk.n;
+    l1p_src SRC;
+    {
+        // shard end relative to the packet's first byte; the copy starts at max(shard end - 64, shard start) (k_fill_tail)
+        const int64_t endrel = (int64_t)(pk.end - pk.src);
+        const uint64_t tn = P.n < 64 ? P.n : 64;
+        SRC.src = pk.src;
+        SRC.lim = endrel - 16 > 0x7fffffff ? 0x7fffffff : (int32_t)(endrel - 16);
+        SRC.tailp = P.tail - (endrel - (int64_t)tn);
+    }
+    const uint32_t NB = (n + ZZ_WAVE - 1) >> 6;                          // blocks of the packet, n > 0
+    lds_u32* const slot = (lds_u32*)tokbuf + lane + pw * ZZ_L1_TOKSLOT;   // block g's tokens go to slot g & 1
+    uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position of the block at hand
+    {
+        const uint32_t p0 = pw * ZZ_WAVE + (uint32_t)lane;
+        l1p_ld128<true>(SRC, p0 < n ? p0 : n - 1, w, w2);
+    }
+    ZZ_PROF_DECL
+    if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
+    for (uint32_t g = pw; g < NB; g += 2) {
+        auto block = [&](auto interior_tag) {
+            // INTERIOR: every lane holds a position with 17+ bytes after it, and the look-ahead load lies inside the packet
+            constexpr bool INT = decltype(interior_tag)::value;
+            const uint32_t base = g << 6;
+            const uint32_t p = base + (uint32_t)lane;
+            const uint32_t nact = INT ? ZZ_WAVE : ((n - base) < ZZ_WAVE ? (n - base) : ZZ_WAVE);
+            const bool active = INT ? true : lane < (int)nact;
+
+            ZZ_T(6); ZZ_C(10, 1);
+            // ---- P1: hash, probe + speculative insert (encoder.cpp:344-346); the candidate's bytes are requested at once
+            const uint32_t h = calc_hash3((uint32_t)(w >> 8));
+            const uint32_t oldraw = T[h];
+            T[h] = (uint16_t)(p + 1);
+            uint64_t wc, wc2;
+            l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(oldraw, 1u), wc, wc2);     // (no candidate: the packet's first bytes, unused)
+            uint64_t wn = 0, wn2 = 0;                                    // this lane's bytes two blocks on: blocks are fixed, so the address is known
+            if (g + 2 < NB) {
+                const uint32_t pn = p + 2 * ZZ_WAVE;
+                l1p_ld128<!INT>(SRC, INT ? pn : (pn < n ? pn : n - 1), wn, wn2);
+            }
+            ZZ_WAVE_SYNC();
+            const uint32_t rb = T[h];                                    // the slot holds whichever lane wrote last
+            // cross lanes: the entry read is a position of block g - 1, entered speculatively while that block is being walked
+            const uint32_t xlo = g ? base - (ZZ_WAVE - 1) : 0xFFFF0000u;
+            const uint32_t qx = oldraw - xlo;                            // its lane there
+            const bool xd = active && qx < ZZ_WAVE;
+#ifdef ZZ_L1P_X_NOCROSS
+            const uint64_t XD = 0;                                       // TIMING EXPERIMENT: no cross lanes at all (wrong streams)
+#else
+            const uint64_t XD = ballot(xd);
+#endif
+            uint32_t talt = 0;
+            uint64_t wa = 0, wa2 = 0;
+            const uint32_t qa = xd ? qx : 0u;
+            if (XD) {
+                // what the table held under this hash BEFORE block g - 1: its owner publishes that, tagged with the block, as soon as
+                // it has settled its own cross lanes (right after B_g-1; this wavefront has repaired block g - 2 since)
+                uint32_t v;
+                do {
+                    ZZ_C(13, 1);
+                    v = *(volatile lds_u32*)&X->told[qa];
+                } while (ballot(xd && (v >> 16) != g));
+                talt = xd ? (v & 0xFFFFu) : 0u;
+                if (xd) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(talt, 1u), wa, wa2);      // (a gather costs the address path per lane)
+            }
+
+            // ---- P2: same-hash sets inside the block, lengths against every possible candidate (16 bytes compared)
+            const uint64_t lostmask = ballot(active && rb != (uint32_t)(uint16_t)(p + 1));
+            const uint32_t left = active ? n - p : 0;
+            const uint32_t cap17 = INT ? 8u * (ZZ_WI_CAP + 1) : (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;
+            uint64_t myset = 0;
+            uint32_t infoB = 0;
+            if (lostmask) {
+                uint32_t W = (uint32_t)lane;
+                if (active) W = (rb - 1u - base) & 63u;
+                myset = wave_match6(W);
+                const uint64_t below = myset & below_me;
+                const bool dup = below != 0 && active;
+                const uint32_t ql = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+                const int qa = (int)(ql << 2);
+                const uint64_t wq = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w);
+                const uint64_t wq2 = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w2 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w2);
+                const uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
+                const bool hard = (uint32_t)__builtin_popcountll(below) > 1u;
+                const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | (hard ? ZZ_WI_HARD : 0u)
+                                    | (lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT));
+                infoB = dup ? di : 0u;
+            }
+            // (the lengths against the table's candidates: on whichever side of the barrier balances the two wavefronts)
+            uint64_t x = 0, xa = 0;
+            uint32_t infoM = 0, infoA = 0;
+            auto lengths = [&]() {
+                x = w ^ wc;
+                uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
+                if (!oldraw) la = 0;
+                infoM = infoB | (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la);
+                infoA = infoM;
+                if (XD) {
+                    xa = w ^ wa;
+                    uint32_t la2 = equal_bits128(xa, w2 ^ wa2, cap17) >> 3;
+                    if (!talt) la2 = 0;
+                    infoA = infoB | (la2 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la2);
+                }
+            };
+            if (!ZZ_L1P_LEN_LATE) lengths();
+
+            ZZ_T(0);
+            l1_group_barrier();                                          // B_g: block g - 1 has been walked
+            if (ZZ_L1P_PRIO_W != ZZ_L1P_PRIO_F) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_W);
+            ZZ_T(1);
+
+            // ---- R: which of its lanes the walk of block g - 1 visited settles the cross lanes
+            uint32_t cin;
+            uint32_t told = oldraw, info;
+            uint32_t xkind = 0;                                          // per lane: 1 = the candidate's first eight bytes XOR mine are in xa, not in x; 2 = its bytes are in xl
+            uint64_t xl = 0;
+            {
+                const uint32_t sc = X->scal[0];
+                const uint32_t r = XD ? X->win[qa] : 0u;                 // the highest visited lane of block g - 1 with my hash (0x80: none)
+                // q itself (the highest lane of its set: the LDS leaves the highest lane's store in the slot): the candidate compared
+                // first; nobody: the entry from before the block, compared second; a lower lane: its bytes are not here
+                const bool use3 = xd && (r & 0x80u);
+                const bool ldm = xd && !use3 && r != qa;
+                const uint32_t toldh = base - ZZ_WAVE + r + 1u;
+                told = use3 ? talt : (ldm ? toldh : oldraw);
+                // the block behind is waiting for this (its cross lanes' second candidate): out first
+                X->told[lane] = told | ((g + 1) << 16);
+                if (ZZ_L1P_LEN_LATE) lengths();
+                cin = uniform(sc);
+                info = use3 ? infoA : infoM;
+                xkind = use3 ? 1u : 0u;
+                if (XD && ballot(ldm)) {
+                    ZZ_C(14, 1);
+                    if (ldm) {
+                        xl = load64(l1p_addr<!INT>(SRC, toldh - 1));       // requested now, used if the walk gets to this lane (its out-of-line path): no wait here
+                        info = infoB | ZZ_WI_HARD | ZZ_WI_EXTA | ZZ_WI_CAP;   // (out of the scalar loop)
+                        xkind = 2u;
+                    }
+                }
+            }
+            const uint64_t E = ballot((info & (ZZ_WI_HARD | 0x1Cu | (0x1Cu << ZZ_WI_LENB_SHIFT))) != 0);
+            {
+                const uint32_t endl = (uint32_t)lane + (info & 31u);
+                const uint64_t m = E >> (endl & 63u);
+                const uint32_t nx = endl + (m ? (uint32_t)__builtin_ctzll(m) : 64u);
+                info |= ((nx < 64u ? nx : 64u) & 63u) << ZZ_WI_NEXT_SHIFT;
+            }
+
+            ZZ_T(2); ZZ_C(12, (uint32_t)__builtin_popcountll(E)); ZZ_C(15, cin < 64 ? cin : 64);
+            // ---- W: the walk (encoder.cpp:341-368 replayed over the event mask), starting behind the match carried in
+            uint64_t mst = 0, usedB = 0;
+            uint64_t cov = cin >= ZZ_WAVE ? ~0ull : ((1ull << cin) - 1);
+            l1_walk_x Xw;
+            Xw.hash = h; Xw.wlo = (uint32_t)w; Xw.whi = (uint32_t)(w >> 32); Xw.candbase = base + 1; Xw.hardok = INT ? 1u : 0u;
+            Xw.ovlen = 0; Xw.ovcand1 = 0; Xw.ovmL = 0; Xw.ovmC = 0;
+            uint32_t& ovlen = Xw.ovlen; uint32_t& ovcand1 = Xw.ovcand1;
+            uint64_t& ovmL = Xw.ovmL; uint64_t& ovmC = Xw.ovmC;
+            uint32_t pos = cin;
+            l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB, Xw);
+            while (pos < nact) {
+                const int e = (int)pos;
+                ZZ_C(11, 1);
+                const uint64_t probed = ~cov | mst;
+                const uint32_t inf = readlane(info, e);
+                const uint32_t pe = base + (uint32_t)e;
+                const uint32_t maxlen = (n - pe) < ZZ_MAX_LEN ? (n - pe) : ZZ_MAX_LEN;
+                uint32_t mlen;
+                if (!(inf & ZZ_WI_HARD)) {
+                    const bool useB = (inf & ZZ_WI_DUP) && ((probed >> ZZ_WI_QLANE(inf)) & 1);
+                    mlen = useB ? ZZ_WI_LENB(inf) : ZZ_WI_LENA(inf);
+                    if (mlen >= 4) {
+                        if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
+                            const uint32_t cand = useB ? base + ZZ_WI_QLANE(inf) : readlane(told, e) - 1;
+                            mlen = l1p_extend_match(SRC, pe, cand, maxlen, ZZ_WI_CAP);
+                            if (lane == e) ovlen = mlen | 0x8000u;
+                            ovmL |= 1ull << e;
+                        }
+                        if (useB) usedB |= 1ull << e;
+                    }
+                } else {
+                    // candidate = most recent visited lane of this block with my hash, else the table's
+                    const uint64_t S = readlane64(myset, e) & probed & ((1ull << e) - 1);
+                    uint32_t cand1 = 0;
+                    uint64_t xe = ~0ull;
+                    if (S) {
+                        const int c = 63 - __builtin_clzll(S);
+                        cand1 = base + (uint32_t)c + 1;
+                        xe = readlane64(w, e) ^ readlane64(w, c);
+                    } else {
+                        cand1 = readlane(told, e);
+                        if (cand1) {
+                            const uint32_t kind = readlane(xkind, e);
+                            xe = kind == 2 ? readlane64(w, e) ^ readlane64(xl, e) : (kind ? readlane64(xa, e) : readlane64(x, e));
+                        }
+                    }
+                    mlen = 0;
+                    if ((uint32_t)xe == 0 && maxlen >= 4) {
+                        if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
+                        else mlen = l1p_extend_match(SRC, pe, cand1 - 1, maxlen);
+                        if (mlen > maxlen) mlen = maxlen;
+                    }
+                    if (lane == e) { ovlen = mlen | 0x8000u; ovcand1 = cand1; }
+                    ovmL |= 1ull << e; ovmC |= 1ull << e;
+                }
+                if (mlen > 3) {                                          // encoder.cpp:356
+                    mst |= 1ull << e;
+                    cov |= (mlen >= 64u - (uint32_t)e) ? (~0ull << e) : (((1ull << mlen) - 1) << e);
+                    pos = (uint32_t)e + mlen;                            // encoder.cpp:361-362
+                } else {
+                    pos = (uint32_t)e + 1;                               // a literal after all (encoder.cpp:367)
+                }
+                l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB, Xw);
+            }
+            ZZ_T(3);
+            // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
+            uint64_t committed;
+            {
+                uint32_t t;
+                asm("s_min_u32 %1, %2, 64\n\ts_sub_u32 %1, 64, %1\n\ts_lshr_b64 %0, -1, %1\n\ts_andn2_b64 %0, %0, %3\n\ts_or_b64 %0, %0, %4"
+                    : "=&s"(committed), "=&s"(t) : "s"(pos), "s"(cov), "s"(mst) : "scc");
+            }
+            {
+                // for the block behind: per lane the highest visited lane with its hash; the match end carried over
+                const uint64_t sv = (myset | (1ull << lane)) & committed;
+                X->win[lane] = (uint8_t)(sv ? 63u - (uint32_t)__builtin_clzll(sv) : 0x80u);
+                if (lane == 0) X->scal[0] = pos > ZZ_WAVE ? pos - ZZ_WAVE : 0u;
+            }
+            ZZ_T(4);
+            l1_group_barrier();                                          // B_g+1: block g has been walked
+            if (ZZ_L1P_PRIO_W != ZZ_L1P_PRIO_F) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_F);
+            ZZ_T(5);
+
+            // ---- P4: table repair where the slot still holds a position of this block (block g + 1 has entered its own since)
+            // (the tokens go to the slot only now: the emitter reads block g - 2's from it after B_g, with nothing but its own
+            // pace between that barrier and the read)
+            const uint32_t rb2 = T[h];
+            {
+                const uint32_t la_ = ZZ_WI_LENA(info) | 0x8000u, lb_ = ZZ_WI_LENB(info) | 0x8000u;     // ZZ_TOK_MATCH >> 16 rides along
+                const uint32_t tl = sel_lanes(ovmL, ovlen, sel_lanes(usedB, lb_, la_));
+                const uint32_t cn = sel_lanes(ovmC, ovcand1, sel_lanes(usedB, base + ZZ_WI_QLANE(info) + 1, told));
+                const uint32_t tmatch = (tl << 16) | (p + 1 - cn);
+                const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
+                *slot = keep_lanes(committed, sel_lanes(mst, tmatch, tlit));
+            }
+            const uint64_t INB = ballot((rb2 - (base + 1)) < ZZ_WAVE);
+            const uint32_t taddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)(T + h);
+            {
+                const uint64_t rm = INB & ~committed;                    // skipped lanes restore the old entry
+                uint64_t saved;
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(rm), "v"(taddr), "v"(told) : "memory", "scc");
+            }
+            if (lostmask) {                                              // among visited lanes sharing a hash the highest position wins
+                ZZ_WAVE_SYNC();
+                const uint64_t wm = ballot((myset & committed & above_me) == 0) & committed & INB;
+                uint64_t saved;
+                asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(wm), "v"(taddr), "v"(p + 1) : "memory", "scc");
+            }
+            ZZ_WAVE_SYNC();
+            w = wn;
+            w2 = wn2;
+        };
+        if ((g << 6) + 3 * ZZ_WAVE + 15 <= n) block(std::true_type{});
+        else block(std::false_type{});
+    }
+    if (((NB - 1) & 1u) != pw) l1_group_barrier();                       // the other wavefront's last walk
+    l1_group_barrier();                                                  // hand-over of the last block's tokens
+    ZZ_PROF_FLUSH(P);
+}
+
+__device__ __forceinline__ void l1p_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf, l1p_xch* X, uint32_t pw)
+{
+    const int lane = lane_id();
+    const l1_pk q = l1_packet_of(P, k);
+    __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_F);
+    // cold table (encoder.cpp:533-536): each parser clears its half
+    uint4* t4 = (uint4*)T + pw * (ZZ_HASH_SIZE * sizeof(uint16_t) / 32);
+    for (int i = lane; i < (int)(ZZ_HASH_SIZE * sizeof(uint16_t) / 32); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
+    if (pw == 0 && lane < 4) X->scal[lane] = 0;                          // block 0: nothing carried in
+    if (pw == 0) X->told[lane] = 0;                                      // (tag 0: no block's)
+    l1_group_barrier();                                                  // B_z
+    if (q.n > 0) {
+        l1p_parse(P, q, T, tokbuf, X, pw);
+    }
+}
+
+__device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, uint32_t k, uint32_t* ring_words, const uint32_t* tokbuf)
+{
+    const int lane = lane_id();
+    const l1_pk q = l1_packet_of(P, k);
+    bitring ring;
+    if (ZZ_L1P_PRIO_E) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_E);
+    ring_init(ring, ring_words, q.out);
+    l1_group_barrier();                                                  // B_z
+    if (P.cks_kind == ZZ_CKS_ADLER) {                                    // while the parsers work on their first blocks
+        zz_cks c = wave_adler(q.src, q.len);
+        if (lane == 0) P.cks[k] = c;
+    }
+    if (q.n > 0) {
+        ring_append_uniform(ring, (q.is_final ? 1u : 0u) | (1u << 1), 3);           // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
+        const uint32_t NB = (q.n + ZZ_WAVE - 1) >> 6;
+        const lds_u32* slot = (const lds_u32*)tokbuf + lane;
+        l1_group_barrier();                                              // B_0
+        l1_group_barrier();                                              // B_1
+        for (uint32_t g = 0; g < NB; ++g) {
+            l1_group_barrier();                                          // B_g+2: block g's tokens are in slot g & 1
+            const uint32_t tok = *slot;
+            slot = lds_flip_slot((lds_u32*)slot);
+            l1_emit_tokens(ring, nullptr, tok);
+        }
+        ring_append_uniform(ring, 0, 7);                                 // EOB: codes_f[256] (encoder.cpp:371)
+    }
+    if (!q.is_final) {
+        // SetLevel(0); AddData(e-1, e): one stored byte = byte alignment (zzflate.cpp:118-120, encoder.cpp:482-502)
+        ring_append_uniform(ring, 0, 3);
+        ring_pad_to_byte(ring);
+        ring_append_uniform(ring, 0xFFFE0001u, 32);
+        ring_append_uniform(ring, q.src[q.len - 1], 8);
+    } else if (q.n == 0) {
+        ring_append_uniform(ring, 1u | (1u << 1), 3);                    // empty final packet: one empty fixed block (D8)
+        ring_append_uniform(ring, 0, 7);
+    }
+    const uint32_t bytes = ring_finish(ring);
+    if (lane == 0) {
+        P.sizes[k] = bytes;
+        if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+    }
+}
+
+// (96 scalar registers: seven wavefronts per SIMD, i.e. the 27 of nine workgroups on a CU; 97..112 would admit six)
+__global__ __launch_bounds__(ZZ_L1P_THREADS) void k_encode_l1p(zz_packet_params P)
+{
+    __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
+    __shared__ uint32_t ring_words[ZZ_RING_WORDS];
+    __shared__ __attribute__((aligned(512))) uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
+    __shared__ l1p_xch X;
+    const uint32_t k = blockIdx.x;
+    const uint32_t wv = uniform(threadIdx.x >> 6);
+    if (wv < 2) l1p_packet_parser(P, k, T, tokbuf, &X, wv);
+    else l1p_packet_emitter(P, k, ring_words, tokbuf);
+}
+
+}  // namespace zz
