@@ -41,7 +41,11 @@ namespace zz {
 // between "walk" and "probe" intervals, and an interval lasts as long as the longer of the two
 #ifndef ZZ_L1P_PRIO_W
 #define ZZ_L1P_PRIO_W 3         // issue priority while a wavefront resolves and walks (the packet's critical path) ...
+#endif
+#ifndef ZZ_L1P_PRIO_F
 #define ZZ_L1P_PRIO_F 1         // ... while it repairs and probes ...
+#endif
+#ifndef ZZ_L1P_PRIO_E
 #define ZZ_L1P_PRIO_E 0         // ... and of the emitter
 #endif
 #ifndef ZZ_L1P_LEN_LATE
@@ -212,7 +216,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             // ---- R: which of its lanes the walk of block g - 1 visited settles the cross lanes
             uint32_t cin;
             uint32_t told = oldraw, info;
-            uint32_t xkind = 0;                                          // per lane: 1 = the candidate's first eight bytes XOR mine are in xa, not in x; 2 = its bytes are in xl
+            uint32_t xkind = 0;                                          // per lane: the candidate's first eight bytes XOR mine are in x (0), xa (1), xl (2)
             uint64_t xl = 0;
             {
                 const uint32_t sc = X->scal[0];
@@ -231,9 +235,16 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 xkind = use3 ? 1u : 0u;
                 if (XD && ballot(ldm)) {
                     ZZ_C(14, 1);
+                    // a lower lane of block g - 1: its bytes come from the cache now (that block's owner has just read them) and the
+                    // walk waits for them here -- still cheaper than its out-of-line path, which such a lane took until it was measured
+                    // (2 per block of DNA-like data, 1.2 of XML)
+                    uint64_t l0 = 0, l1 = 0;
+                    if (ldm) l1p_ld128<!INT>(SRC, toldh - 1, l0, l1);
+                    const uint64_t x3 = w ^ l0;
+                    const uint32_t la3 = equal_bits128(x3, w2 ^ l1, cap17) >> 3;
                     if (ldm) {
-                        xl = load64(l1p_addr<!INT>(SRC, toldh - 1));       // requested now, used if the walk gets to this lane (its out-of-line path): no wait here
-                        info = infoB | ZZ_WI_HARD | ZZ_WI_EXTA | ZZ_WI_CAP;   // (out of the scalar loop)
+                        xl = x3;
+                        info = infoB | (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3);
                         xkind = 2u;
                     }
                 }
@@ -290,7 +301,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                         cand1 = readlane(told, e);
                         if (cand1) {
                             const uint32_t kind = readlane(xkind, e);
-                            xe = kind == 2 ? readlane64(w, e) ^ readlane64(xl, e) : (kind ? readlane64(xa, e) : readlane64(x, e));
+                            xe = kind == 2 ? readlane64(xl, e) : (kind ? readlane64(xa, e) : readlane64(x, e));
                         }
                     }
                     mlen = 0;
