@@ -553,7 +553,7 @@ def main():
         # wavefront issued flat out; frac = bound_ms / kernel_ms.
         issue = None
         if insts and kms > 0 and args.level >= 1:
-            resident = 256 * (8 if args.level >= 4 else 9) * 2
+            resident = 256 * (8 if args.level >= 4 else 9) * (3 if args.level == 1 else 2)     # level 1: two parsers + the emitter per packet (k_encode_l1p)
             cpi, ghz = 5.0, 2.4
             bound_ms = insts * cpi / (resident * ghz * 1e9) * 1e3
             issue = {"bound": "issue", "instructions": insts, "cycles_per_instruction": cpi, "resident_wavefronts": resident,

@@ -50,7 +50,7 @@ enum {
     ZZ_E_NOSPACE = -2,      /* destination too small */
     ZZ_E_HIP = -3,          /* HIP runtime error / no device */
     ZZ_E_ARG = -4,          /* bad argument (packet size, null pointer) */
-    ZZ_E_UNSUPPORTED = -5   /* reserved */
+    ZZ_E_UNSUPPORTED = -5   /* the device lacks a property the requested mode needs (zz_ctx_set_warm_window, zz_ctx_set_extended_levels) */
 };
 
 #define ZZ_DEFAULT_PACKET 32768u

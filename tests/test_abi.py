@@ -80,6 +80,20 @@ def test_no_cpu_fallback_without_gpu():
         zz.Context(0)
 
 
+def test_lds_order_guard_hook_answers_without_a_device():
+    """The run-time guard for the undocumented LDS ordering (zz_api.hip lds_order_ok): a forced verdict is answered from the host
+    alone, so the refusal path can be driven from a test; the un-forced probe needs a GPU (tests/test_gpu_parity.py)."""
+    L = ctypes.CDLL(zz._build.LIB)
+    L.zz_debug_lds_order_verdict.restype = ctypes.c_int
+    try:
+        L.zz_debug_force_lds_order(ctypes.c_int(0))
+        assert L.zz_debug_lds_order_verdict(ctypes.c_int(0)) == 0
+        L.zz_debug_force_lds_order(ctypes.c_int(1))
+        assert L.zz_debug_lds_order_verdict(ctypes.c_int(0)) == 1
+    finally:
+        L.zz_debug_force_lds_order(ctypes.c_int(-1))
+
+
 def test_product_does_not_touch_oracle():
     """The shipped package must not import, link or open anything under oracle/."""
     pkg = os.path.join(ROOT, "zzflate_amd")

@@ -543,6 +543,41 @@ def test_lds_serves_equal_addresses_in_lane_order(gpu):
     assert checked.value == 512 * 1024 * 6 * 128 and bad.value == 0, (bad.value, checked.value)
 
 
+def test_lds_order_guard_refuses_and_level1_falls_back(gpu, oracle, corpus):
+    """Where the probe's verdict is "does not hold" (forced here through the debug hook), the modes that depend on the LDS's
+    ordering are refused with ZZ_E_UNSUPPORTED and a message, level 1 runs its one-wavefront kernel -- the same bytes as the
+    two-wavefront one and as the oracle --, and levels 0..3 with cold packets are untouched."""
+    import torch
+    ctx = zz.Context(0)
+    assert zz.lib.zz_debug_lds_order_verdict(0) == 1          # the device this runs on passes the probe
+    d = corpus["alice29.txt"] + corpus["kennedy.xls"][:300000]
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = zz.bound(len(d), 0, 1, 32768)
+    dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+
+    def enc(lvl):
+        w = ctx.encode(src, len(d), dst, cap, 0, lvl, 32768)
+        assert ctx.verify_last() == (0, None)
+        return dst[:w].cpu().numpy().tobytes()
+    two = enc(1)
+    assert two == oracle.encode_packets(d, 0, 1, 32768)
+    try:
+        zz.lib.zz_debug_force_lds_order(0)
+        for call in (lambda: ctx.set_warm_window(4096), lambda: ctx.set_extended_levels(True)):
+            with pytest.raises(zz.ZzFlateError) as e:
+                call()
+            assert e.value.code == -5 and "lane order" in str(e.value)
+        ctx.set_warm_window(0)                                 # switching off is always allowed
+        ctx.set_extended_levels(False)
+        assert enc(1) == two                                   # k_encode_l1 instead of k_encode_l1p: the same stream
+        for lvl in (0, 2, 3):
+            assert enc(lvl) == oracle.encode_packets(d, 0, lvl, 32768)
+    finally:
+        zz.lib.zz_debug_force_lds_order(-1)
+    ctx.set_warm_window(4096)                                  # accepted again
+    ctx.set_warm_window(0)
+
+
 def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
     """levels 4, 5, 6 (off unless switched on) = hash chains of depth 2 / 4 / 8 over a window of 8 / 32 /
     32 KiB, one-step lazy matching, package-merge code lengths (zz_level6.h). Bit-exact with the oracle's definition

@@ -304,6 +304,42 @@ extern "C" int zz_debug_lds_atomic_order(zz_ctx* c, uint32_t trials, unsigned lo
     if (checked) *checked = 512ull * 1024ull * 6ull * trials;
     return ZZ_OK;
 }
+// ---- the run-time guard for that property ---------------------------------------------------------------------------------
+// Three things in this library are only correct where the LDS serves equal addresses of one instruction in ascending lane order
+// and one wavefront's instructions in issue order -- which gfx950 does and its ISA manual does not promise: the warm window's
+// pre-hash (zz_level1.h warm_prehash), the extended levels' counting sort (zz_level6.h) and the two-wavefront level-1 kernel
+// (zz_level1p.h: a slot ends up with the HIGHEST lane's store). So the probe above runs once per device, the first time one of
+// them is asked for, and its verdict is kept: where it fails, zz_ctx_set_warm_window(> 0) and zz_ctx_set_extended_levels(1) are
+// refused with ZZ_E_UNSUPPORTED and level 1 runs its one-wavefront kernel (k_encode_l1, which asks the LDS for nothing of the
+// kind); levels 0..3 with cold packets never depend on it. zz_debug_force_lds_order lets a test take the refusal path.
+static std::mutex g_order_mu;
+static int g_order_verdict[64];            // per device: 0 unknown, 1 holds, -1 does not
+static int g_order_forced = -1;            // -1: probe; 0 / 1: the verdict every device gets (tests)
+extern "C" void zz_debug_force_lds_order(int verdict) { std::lock_guard<std::mutex> lk(g_order_mu); g_order_forced = verdict < 0 ? -1 : (verdict ? 1 : 0); }
+static bool lds_order_ok(int device)
+{
+    std::lock_guard<std::mutex> lk(g_order_mu);
+    if (g_order_forced >= 0) return g_order_forced == 1;
+    if (device < 0 || device >= 64) return false;
+    if (g_order_verdict[device] == 0) {
+        unsigned long long bad = 1, *d = nullptr;
+        int prev = 0;
+        bool ran = hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess && hipMalloc(&d, sizeof(bad)) == hipSuccess;
+        if (ran) {
+            ran = hipMemset(d, 0, sizeof(bad)) == hipSuccess;
+            if (ran) {
+                hipLaunchKernelGGL(k_lds_order_probe, dim3(512), dim3(1024), 0, 0, 0xC0FFEEu ^ (uint32_t)device, 4u, d);   // 12.6 M checks, < 1 ms
+                ran = hipGetLastError() == hipSuccess && hipMemcpy(&bad, d, sizeof(bad), hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            (void)hipFree(d);
+            (void)hipSetDevice(prev);
+        }
+        g_order_verdict[device] = (ran && bad == 0) ? 1 : -1;
+    }
+    return g_order_verdict[device] == 1;
+}
+// (not part of the public header) the verdict for a device: 1 holds, 0 does not
+extern "C" int zz_debug_lds_order_verdict(int device) { return lds_order_ok(device) ? 1 : 0; }
 // diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
 extern "C" int zz_debug_read_prof(zz_ctx* c, unsigned long long out[16])
 {
@@ -319,6 +355,10 @@ extern "C" int zz_ctx_set_warm_window(zz_ctx* c, uint32_t bytes)
 {
     if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
     if (bytes > 32768) { set_err("warm window must be 0..32768 bytes"); return ZZ_E_ARG; }
+    if (bytes && !lds_order_ok(c->device)) {
+        set_err("warm window refused: this device's LDS does not serve equal addresses in lane order (probe k_lds_order_probe failed)");
+        return ZZ_E_UNSUPPORTED;
+    }
     c->warm = bytes;
     return ZZ_OK;
 }
@@ -327,6 +367,10 @@ extern "C" int zz_ctx_set_warm_window(zz_ctx* c, uint32_t bytes)
 extern "C" int zz_ctx_set_extended_levels(zz_ctx* c, int on)
 {
     if (!c) { set_err("null ctx"); return ZZ_E_ARG; }
+    if (on && !lds_order_ok(c->device)) {
+        set_err("extended levels refused: this device's LDS does not serve equal addresses in lane order (probe k_lds_order_probe failed)");
+        return ZZ_E_UNSUPPORTED;
+    }
     c->extended = on != 0;
     return ZZ_OK;
 }
@@ -448,7 +492,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             // k_encode_l1p; the streams are the same
             static const bool classic = [] { const char* e = getenv("ZZFLATE_L1_KERNEL"); return e && !strcmp(e, "classic"); }();
             if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
-            else if (classic) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            else if (classic || !lds_order_ok(c->device)) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
             else {
                 hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);
                 hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
@@ -1026,6 +1070,10 @@ static int pool_acquire(int device, int held, bool nested, zz_ctx** out, bool* t
             return (uint32_t)(v < 0 ? 0 : v > 32768 ? 32768 : v);
         }();
         static const bool ext = [] { const char* e = getenv("ZZFLATE_EXTENDED_LEVELS"); return e && atoi(e) != 0; }();
+        if ((warm || ext) && !lds_order_ok(device)) {   // (the same refusal as zz_ctx_set_warm_window / zz_ctx_set_extended_levels)
+            set_err("ZZFLATE_WARM_WINDOW / ZZFLATE_EXTENDED_LEVELS refused: this device's LDS does not serve equal addresses in lane order");
+            return ZZ_E_UNSUPPORTED;
+        }
         for (auto& e : g_pool)
             if (e.c->device == device) {
                 if (!e.busy) { e.busy = true; e.c->warm = warm; e.c->extended = ext; *out = e.c; return ZZ_OK; }

@@ -14,12 +14,12 @@
 // while block g is still being walked, i.e. against a table that holds block g's SPECULATIVE entries (every position of
 // g entered; the walk has not said yet which of them the reference would have entered). That is resolved exactly:
 //   * a lane of g + 1 whose table read returns a position of block g ("cross lane", about a quarter of the lanes of text)
-//     has two possible candidates -- that position q if the walk of g visits it, else what the table held before block g
-//     under that hash (told_g[q], which block g's owner publishes as soon as it has resolved its own lanes) -- and
-//     compares against both before the walk of g has finished; the moment it has, one bit test per lane picks the
-//     right one (`R` below). If q is skipped but an earlier lane of g with the same hash is visited (rare: the chain of
-//     "nearest earlier lane with my hash" that g's owner publishes is followed), the lane is settled by the walk's
-//     out-of-line path with a load, like a lane whose hash occurs three times in its own block.
+//     has two likely candidates -- that position q if the walk of g visits it, else what the table held before block g
+//     under that hash (told_g[q], which block g's owner publishes, tagged with the block, as soon as it has settled its
+//     own cross lanes) -- and compares against both before the walk of g has finished. When it has, g's owner publishes
+//     per lane the highest VISITED lane of the block with that lane's hash (`win`), and one gathered byte per cross lane
+//     picks: q itself, nobody (the older entry), or -- rarely -- a lower lane of g, whose bytes are then fetched from the
+//     cache and compared on the spot (`R` below).
 //   * repair of block g (skipped lanes restore the old entry, the highest visited lane per hash wins: the state the
 //     serial loop leaves) runs after block g + 1 has entered its positions, so it only touches slots that still hold
 //     a position of block g; a slot block g + 1 has overwritten is that block's to repair, from its resolved old entry.
@@ -28,9 +28,13 @@
 // with the HIGHEST position of the block under that hash): zz_ctx probes that once per device and falls back to
 // k_encode_l1 where it does not hold (zz_api.hip, lds_order_ok).
 //
-// Hand-over between the two parsers goes through 352 bytes of LDS (l1p_xch) and one s_barrier per block, which the
+// Hand-over between the two parsers goes through 336 bytes of LDS (l1p_xch) and one s_barrier per block, which the
 // emitter wavefront (the third of the workgroup: Adler-32, fixed-Huffman coding, bit packing -- as in k_encode_l1) joins.
-// LDS: 16,384 table + 512 ring + 512 token slots + 352 = 17,760 bytes <= 17,920: nine workgroups per CU, 27 wavefronts.
+// LDS: 16,384 table + 512 ring + 512 token slots + 336 = 17,744 bytes <= 17,920: nine workgroups per CU, 27 wavefronts
+// (56 VGPRs, 65 SGPRs: the 27 fit whatever SIMDs the workgroups' wavefronts land on).
+// Measured (profiles/README.md, round 4): 1 GiB text 119 -> 123-124 GB/s, log lines 96 -> 117, the twelve-family mix
+// 102.5 -> 106; the optimistic bound of this shape (tools/pipe_probe.sh: no cross lanes, no exchange) is 159, and what the
+// exact cross-lane resolution costs is 17 % (the same kernel without it: 145-148 GB/s, wrong streams).
 #pragma once
 #include "zz_level1.h"
 
@@ -120,8 +124,31 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
         l1p_ld128<true>(SRC, p0 < n ? p0 : n - 1, w, w2);
     }
     ZZ_PROF_DECL
+    uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
     for (uint32_t g = pw; g < NB; g += 2) {
+        if (mycout >= 2 * ZZ_WAVE) {
+            // A match found two blocks ago covers this block entirely (and the one between, which the other wavefront had probed by
+            // then): nothing is probed, entered or walked -- the barriers, the carried match end and an empty token slot are all there
+            // is. What keeps long runs (zeros: 258 bytes per match, four blocks) from costing four blocks' work each.
+            const uint32_t p = (g << 6) + (uint32_t)lane;
+            uint64_t wn = 0, wn2 = 0;
+            if (g + 2 < NB) {
+                const uint32_t pn = p + 2 * ZZ_WAVE;
+                l1p_ld128<true>(SRC, pn < n ? pn : n - 1, wn, wn2);
+            }
+            l1_group_barrier();                                          // B_g
+            const uint32_t cin = uniform(X->scal[0]);                    // (>= 64: the block in front was covered too)
+            mycout = cin > ZZ_WAVE ? cin - ZZ_WAVE : 0u;
+            X->win[lane] = 0x80;
+            X->told[lane] = (g + 1) << 16;
+            if (lane == 0) X->scal[0] = mycout;
+            l1_group_barrier();                                          // B_g+1
+            *slot = 0;
+            w = wn;
+            w2 = wn2;
+            continue;
+        }
         auto block = [&](auto interior_tag) {
             // INTERIOR: every lane holds a position with 17+ bytes after it, and the look-ahead load lies inside the packet
             constexpr bool INT = decltype(interior_tag)::value;
@@ -334,7 +361,8 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 // for the block behind: per lane the highest visited lane with its hash; the match end carried over
                 const uint64_t sv = (myset | (1ull << lane)) & committed;
                 X->win[lane] = (uint8_t)(sv ? 63u - (uint32_t)__builtin_clzll(sv) : 0x80u);
-                if (lane == 0) X->scal[0] = pos > ZZ_WAVE ? pos - ZZ_WAVE : 0u;
+                mycout = pos > ZZ_WAVE ? pos - ZZ_WAVE : 0u;
+                if (lane == 0) X->scal[0] = mycout;
             }
             ZZ_T(4);
             l1_group_barrier();                                          // B_g+1: block g has been walked
@@ -439,7 +467,6 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
     }
 }
 
-// (96 scalar registers: seven wavefronts per SIMD, i.e. the 27 of nine workgroups on a CU; 97..112 would admit six)
 __global__ __launch_bounds__(ZZ_L1P_THREADS) void k_encode_l1p(zz_packet_params P)
 {
     __shared__ uint16_t T[ZZ_HASH_SIZE];          // hashtable (encoder.h:76) as pos+1, 0 = empty
