@@ -379,6 +379,20 @@ def test_multi_device_entry_point_equals_the_single_call(gpu, oracle, corpus, lv
         w = zz.encode_multi(ctxs, srcs, ns, dst, cap, fmt, lvl, P, halos=halos)
         got = dst[:w].cpu().numpy().tobytes()
         assert got == oracle.encode_packets(d, fmt, lvl, P), (lvl, fmt)
+    # the pulls' way is asked for once per device pair and reported: same device = no peer needed; on a box with several
+    # GPUs the second call must find the pair already enabled (idempotent) and count its pulls as peer to peer or staged
+    import ctypes
+    p2p, staged = ctypes.c_int(-1), ctypes.c_int(-1)
+    zz.lib.zz_debug_last_pulls(ctypes.byref(p2p), ctypes.byref(staged))
+    assert p2p.value + staged.value == 2 and zz.lib.zz_debug_peer_state(0, 0) == 1
+    if torch.cuda.device_count() > 1:
+        c1 = zz.Context(1)
+        with torch.cuda.device(1):
+            t1 = keep[1].to("cuda:1")
+        for _ in range(2):
+            w2 = zz.encode_multi([ctxs[0], c1], [srcs[0], t1[halos[1]:]], [ns[0], ns[1]], dst, cap, 0, lvl, P, halos=[0, halos[1]])
+            assert dst[:w2].cpu().numpy().tobytes() == oracle.encode_packets(d[:cuts[2]], 0, lvl, P)
+            assert zz.lib.zz_debug_peer_state(0, 1) in (1, -1)
     # too small a destination is reported, and the contexts stay usable
     dst = torch.zeros(1000, dtype=torch.uint8, device="cuda")
     with pytest.raises(zz.ZzFlateError):

@@ -1,6 +1,7 @@
 """Extended seeded fuzz against the oracle (manual; the pytest suite runs a 120-case version): packet mode (cold, warm
 window, extended levels), the sequential stream into roomy and tight destinations, the callback form's chunks.
-python tools/fuzz_gpu.py [cases] [seed]
+python tools/fuzz_gpu.py [cases] [seed] [--seconds S]     stops by itself after S seconds (exit 0 unless a case was bad), so that a
+                                                          run under a time box ends with its own summary line, not with the box's kill
 ZZ_FUZZ_DUMP=<case> python tools/fuzz_gpu.py [cases] [seed]   (no GPU needed) writes that case's input to gpurun_out/fuzz_case_<case>.in"""
 import os, random, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,12 +12,18 @@ from conftest import Oracle, synth, SYNTH_KINDS
 DUMP = int(os.environ.get("ZZ_FUZZ_DUMP", "-1"))
 o = Oracle()
 ctx = zz.Context(0) if DUMP < 0 else None
+BUDGET = None
+if "--seconds" in sys.argv:
+    i = sys.argv.index("--seconds"); BUDGET = float(sys.argv[i + 1]); del sys.argv[i:i + 2]
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 WB = {0: 15, 1: 31, 2: -15}
 kinds = SYNTH_KINDS + ["longperiod"]
 t0 = time.time(); bad = 0
+done = 0
 for it in range(cases):
+    if BUDGET is not None and time.time() - t0 > BUDGET: break
+    done = it + 1
     kind = rng.choice(kinds)
     n = rng.choice([rng.randint(1, 300), rng.randint(300, 40000), rng.randint(40000, 400000)])
     d = synth(kind, n, 10000 + it)
@@ -103,5 +110,5 @@ for it in range(cases):
             bad += 1
             print("MISMATCH", it, kind, len(d), P, elvl, fmt, warm, vb, flush=True)
     if it % 100 == 99: print(f"{it + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
-print("bad", bad)
+print(f"{done} cases in {time.time() - t0:.0f} s" + (f" (time budget {BUDGET:.0f} s)" if BUDGET is not None else "") + f", bad {bad}")
 sys.exit(1 if bad else 0)

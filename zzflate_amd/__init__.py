@@ -95,6 +95,8 @@ def _load():
         "zz_debug_host_staging_bytes": (u64, []),
         "zz_debug_lds_atomic_order": (i32, [vp, u32, pu64, pu64]),
         "zz_debug_force_lds_order": (None, [i32]),
+        "zz_debug_peer_state": (i32, [i32, i32]),
+        "zz_debug_last_pulls": (None, [ctypes.POINTER(i32), ctypes.POINTER(i32)]),
         "zz_debug_lds_order_verdict": (i32, [i32]),
         "zz_last_error": (ctypes.c_char_p, []),
         "zz_version": (ctypes.c_char_p, []),

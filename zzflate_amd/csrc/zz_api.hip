@@ -855,6 +855,48 @@ extern "C" int zz_trailer(int format, uint32_t v, uint64_t n, uint8_t out[8]);
 // shard i finishes, its compressed bytes are pulled over xGMI (hipMemcpyPeerAsync) straight to their final offset in
 // d_dst, which lives on the device of ctxs[0] (shard 0 is encoded in place there); the checksum partials are folded on
 // the host (adler.cpp:5-15 / GF(2) shifts) and header and trailer are written around the stream. No bulk collective.
+// ---- peer access for the pulls of zz_encode_multi_device ------------------------------------------------------------------
+// hipMemcpyPeerAsync works with or without peer access; without it the copy is staged through host memory instead of going
+// over xGMI. So: once per ordered device pair (src -> dst), ask hipDeviceCanAccessPeer and enable access both ways; the answer
+// is kept, "already enabled" counts as enabled, and zz_debug_peer_state tells a caller (and the tests) what a pull will use.
+static std::mutex g_peer_mu;
+static signed char g_peer[64][64];          // [dst][src]: 0 unknown, 1 peer access enabled, -1 not available (copies are staged)
+static int peer_prepare(int dst, int src)
+{
+    if (dst == src) return 1;
+    if (dst < 0 || src < 0 || dst >= 64 || src >= 64) return -1;
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    if (g_peer[dst][src] == 0) {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        bool ok = true;
+        for (int dir = 0; dir < 2 && ok; ++dir) {                    // dst reads/writes src's memory and the other way round
+            const int a = dir ? src : dst, b = dir ? dst : src;
+            int can = 0;
+            ok = hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can != 0 && hipSetDevice(a) == hipSuccess;
+            if (ok) {
+                const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();      // idempotent: clear the sticky error
+                else ok = e == hipSuccess;
+            }
+        }
+        (void)hipSetDevice(prev);
+        g_peer[dst][src] = g_peer[src][dst] = ok ? 1 : -1;
+    }
+    return g_peer[dst][src];
+}
+// (not part of the public header) 1: pulls from `src` to `dst` go peer to peer; -1: staged through the host; 0: not asked yet
+extern "C" int zz_debug_peer_state(int dst, int src)
+{
+    if (dst == src) return 1;
+    if (dst < 0 || src < 0 || dst >= 64 || src >= 64) return -1;
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    return g_peer[dst][src];
+}
+// (not part of the public header) how many of the last zz_encode_multi_device call's pulls (this thread) went peer to peer / were staged
+static thread_local int tl_pulls_p2p = 0, tl_pulls_staged = 0;
+extern "C" void zz_debug_last_pulls(int* p2p, int* staged) { if (p2p) *p2p = tl_pulls_p2p; if (staged) *staged = tl_pulls_staged; }
+
 extern "C" int zz_encode_multi_device(zz_ctx* const* ctxs, int nshards, const void* const* d_src, const uint64_t* n,
                                       const uint64_t* halo, void* d_dst, uint64_t cap, uint64_t* out_len, int format, int level,
                                       uint32_t P)
@@ -874,6 +916,9 @@ extern "C" int zz_encode_multi_device(zz_ctx* const* ctxs, int nshards, const vo
     if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
     uint8_t* dst = (uint8_t*)d_dst;
     zz_ctx* c0 = ctxs[0];
+    // the pulls' way: peer access between the first device and every other one, asked for and enabled once per pair
+    tl_pulls_p2p = tl_pulls_staged = 0;
+    for (int i = 1; i < nshards; ++i) (void)peer_prepare(c0->device, ctxs[i]->device);
     // enqueue every shard on its own device and stream; nothing waits yet
     std::vector<uint64_t> bound(nshards);
     for (int i = 0; i < nshards; ++i) {
@@ -910,6 +955,7 @@ extern "C" int zz_encode_multi_device(zz_ctx* const* ctxs, int nshards, const vo
                 hipMemcpyPeerAsync(dst + off, c0->device, c->stage_out, c->device, w, c->s_enc) != hipSuccess) {
                 err = ZZ_E_HIP; errmsg = "hipMemcpyPeerAsync failed"; continue;
             }
+            if (peer_prepare(c0->device, c->device) == 1) tl_pulls_p2p++; else tl_pulls_staged++;
         }
         acc = format == ZZ_ZLIB ? adler_combine(acc, part, n[i]) : format == ZZ_GZIP ? crc32_combine(acc, part, n[i]) : 0u;
         off += w;

@@ -52,9 +52,6 @@ namespace zz {
 #ifndef ZZ_L1P_PRIO_E
 #define ZZ_L1P_PRIO_E 0         // ... and of the emitter
 #endif
-#ifndef ZZ_L1P_LEN_LATE
-#define ZZ_L1P_LEN_LATE 0       // 1: the lengths against the table's candidates behind the barrier, in the walk's interval
-#endif
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 struct l1p_xch {
@@ -217,49 +214,35 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                                     | (lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT));
                 infoB = dup ? di : 0u;
             }
-            // (the lengths against the table's candidates: on whichever side of the barrier balances the two wavefronts)
-            uint64_t x = 0, xa = 0;
-            uint32_t infoM = 0, infoA = 0;
-            auto lengths = [&]() {
-                x = w ^ wc;
-                uint32_t la = equal_bits128(x, w2 ^ wc2, cap17) >> 3;
-                if (!oldraw) la = 0;
-                infoM = infoB | (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la);
-                infoA = infoM;
-                if (XD) {
-                    xa = w ^ wa;
-                    uint32_t la2 = equal_bits128(xa, w2 ^ wa2, cap17) >> 3;
-                    if (!talt) la2 = 0;
-                    infoA = infoB | (la2 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la2);
-                }
-            };
-            if (!ZZ_L1P_LEN_LATE) lengths();
-
             ZZ_T(0);
             l1_group_barrier();                                          // B_g: block g - 1 has been walked
             if (ZZ_L1P_PRIO_W != ZZ_L1P_PRIO_F) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_W);
             ZZ_T(1);
 
-            // ---- R: which of its lanes the walk of block g - 1 visited settles the cross lanes
+            // ---- R: which of its lanes the walk of block g - 1 visited settles the cross lanes; then ONE comparison per lane,
+            // against the candidate that is the right one (this side of the barrier on purpose: the interval in which the other
+            // wavefront repairs, probes and builds its same-hash sets is the longer of the two)
             uint32_t cin;
-            uint32_t told = oldraw, info;
-            uint32_t xkind = 0;                                          // per lane: the candidate's first eight bytes XOR mine are in x (0), xa (1), xl (2)
-            uint64_t xl = 0;
+            uint32_t told, info;
+            uint64_t x;                                                  // the candidate's first eight bytes XOR mine
             {
                 const uint32_t sc = X->scal[0];
                 const uint32_t r = XD ? X->win[qa] : 0u;                 // the highest visited lane of block g - 1 with my hash (0x80: none)
-                // q itself (the highest lane of its set: the LDS leaves the highest lane's store in the slot): the candidate compared
-                // first; nobody: the entry from before the block, compared second; a lower lane: its bytes are not here
+                // q itself (the highest lane of its set: the LDS leaves the highest lane's store in the slot): the table's entry as
+                // read; nobody: the entry from before the block; a lower lane: its bytes are not here
                 const bool use3 = xd && (r & 0x80u);
                 const bool ldm = xd && !use3 && r != qa;
                 const uint32_t toldh = base - ZZ_WAVE + r + 1u;
                 told = use3 ? talt : (ldm ? toldh : oldraw);
                 // the block behind is waiting for this (its cross lanes' second candidate): out first
                 X->told[lane] = told | ((g + 1) << 16);
-                if (ZZ_L1P_LEN_LATE) lengths();
+                __builtin_amdgcn_sched_barrier(0);                       // (nothing that waits for the candidates' bytes may move in front of that store)
                 cin = uniform(sc);
-                info = use3 ? infoA : infoM;
-                xkind = use3 ? 1u : 0u;
+                const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
+                x = w ^ c;
+                uint32_t la = equal_bits128(x, w2 ^ c2, cap17) >> 3;
+                if (!told) la = 0;
+                info = infoB | (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la);
                 if (XD && ballot(ldm)) {
                     ZZ_C(14, 1);
                     // a lower lane of block g - 1: its bytes come from the cache now (that block's owner has just read them) and the
@@ -270,9 +253,8 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     const uint64_t x3 = w ^ l0;
                     const uint32_t la3 = equal_bits128(x3, w2 ^ l1, cap17) >> 3;
                     if (ldm) {
-                        xl = x3;
+                        x = x3;
                         info = infoB | (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3);
-                        xkind = 2u;
                     }
                 }
             }
@@ -327,8 +309,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     } else {
                         cand1 = readlane(told, e);
                         if (cand1) {
-                            const uint32_t kind = readlane(xkind, e);
-                            xe = kind == 2 ? readlane64(xl, e) : (kind ? readlane64(xa, e) : readlane64(x, e));
+                            xe = readlane64(x, e);
                         }
                     }
                     mlen = 0;
