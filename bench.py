@@ -144,6 +144,9 @@ def launch_ranks(n):
         # RCCL and device-memory sharing across processes on this pool's host driver, and exported there already; only set
         # when the caller's environment does not say otherwise (never overridden). DESIGN.md 6.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # first contact with a multi-GPU node: whatever RCCL has to say about a failing rank goes to that rank's stderr, which is
+        # this process's (inherited)
+        env.setdefault("NCCL_DEBUG", "WARN")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst = 0
     try:
@@ -152,6 +155,8 @@ def launch_ranks(n):
                 rc = pr.poll()
                 if rc not in (None, 0) and not worst:
                     worst = rc
+                    print(f"bench.py: rank {procs.index(pr)} exited with code {rc}; its stderr (NCCL_DEBUG={os.environ.get('NCCL_DEBUG', 'WARN')}) is above; "
+                          "stopping the other ranks", file=sys.stderr, flush=True)
                     for other in procs:                # a rank died: the others would wait in a collective forever
                         if other.poll() is None:
                             other.terminate()
@@ -187,6 +192,9 @@ def main():
     ap.add_argument("--gather", default="rccl", choices=["rccl", "none"], help="N > 1: 'rccl' (default) = the north star's path, every "
                     "step's compressed shards are gathered onto rank 0; 'none' = encode only, nothing is exchanged (how the "
                     "encoders alone scale). The default line carries the encode-only rate too (`exchange.encode_only`)")
+    ap.add_argument("--gather-root", default="0", choices=["0", "rotate"], help="N > 1: '0' (default) = every step's stream is gathered "
+                    "onto rank 0; 'rotate' = step i's onto rank i mod N (still ONE grouped send/recv per stream), so that a run of "
+                    "streams is not capped by ONE GPU's seven inbound xGMI links")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     args = ap.parse_args()
@@ -247,10 +255,13 @@ def main():
     cap = zz.bound(n, 2, min(args.level, 3), P)
     shard = torch.empty(cap, dtype=torch.uint8, device="cuda")
     xdev = "cuda" if backend == "nccl" else "cpu"     # where the exchange buffers live
-    gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (multi and rank == 0) else None
+    rotate = multi and args.gather_root == "rotate"
+    holds = multi and (rank == 0 or rotate)             # this rank is the gather target of some steps
+    gathered = torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if holds else None
     # step-overlapped mode: a second pair of buffers, so that step i's gather can still be in flight during step i+1
     shard_b = [shard, torch.empty(cap, dtype=torch.uint8, device="cuda") if multi else None]
-    gathered_b = [gathered, torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if (multi and rank == 0) else None]
+    gathered_b = [gathered, torch.empty(cap * world + 32, dtype=torch.uint8, device=xdev) if holds else None]
+    root_b = [0, 0]                                     # the gather target of the stream in each pair of buffers
     pending = [None, None]
     # N > 1, --chunks 1: two contexts on two streams, alternating, so that step i's shard can be enqueued BEFORE step i-1's
     # size and checksum are exchanged (zz_encode_shard_device_async / zz_encode_shard_finish): the host-side part of the
@@ -319,7 +330,7 @@ def main():
             state["out_bytes"] = w * world                  # (nothing assembled: the ratio is this rank's)
             return
         xshard = shard_b[b] if backend == "nccl" else shard_b[b][:w].cpu()
-        pending[b] = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b], wait=False)
+        pending[b] = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b] if rank == root_b[b] else None, wait=False, root=root_b[b])
 
     def step():
         if (not multi):
@@ -340,6 +351,7 @@ def main():
                 pending[b] = None
                 if rank == 0:
                     state["out_bytes"] = tot
+            root_b[b] = ((state["step"] - 1) % world) if rotate else 0
             # (a request's wait() orders the CURRENT stream behind the transfer; the encode runs on a stream of its own and
             # must not overwrite the shard buffer while that send may still be reading it)
             mstream[b].wait_stream(torch.cuda.current_stream())
@@ -432,6 +444,19 @@ def main():
             gms.append((time.perf_counter() - t2) * 1e3)
         g1 = torch.tensor([sum(gms[1:]) / k2], dtype=torch.float64, device="cuda")      # (the first one warms the connections up)
         dist.all_reduce(g1, op=dist.ReduceOp.MAX)
+        # the same exchange onto the LAST rank: with --gather-root rotate every rank takes its turn as the target
+        g2 = None
+        if rotate:
+            gms2 = []
+            for _ in range(k2 + 1):
+                dist.barrier(); torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b] if rank == world - 1 else None, wait=True, root=world - 1)
+                torch.cuda.synchronize()
+                gms2.append((time.perf_counter() - t2) * 1e3)
+            g2 = torch.tensor([sum(gms2[1:]) / k2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(g2, op=dist.ReduceOp.MAX)
+            tot = sharded.gather_stream(dist, fmt, xshard, w, cks, n, gathered_b[b], wait=True)      # rank 0 holds the last stream again (validation)
         if rank == 0:
             state["out_bytes"] = tot
             hl_, tl_ = {0: (2, 4), 1: (10, 8), 2: (0, 0)}[fmt]
@@ -439,7 +464,10 @@ def main():
             e_ms = float(d1.item()) / k2 * 1e3
             exchange = {"gather": "rccl" if backend == "nccl" else backend,
                         "encode_only": {"value": round(total_n / (e_ms * 1e-3) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(e_ms, 3), "steps": k2},
-                        "gather_ms_serial": round(float(g1.item()), 3), "bytes_into_rank0_per_step": inbound,
+                        "gather_root": args.gather_root,
+                        "gather_ms_serial": round(float(g1.item()), 3),
+                        "gather_ms_serial_onto_last_rank": round(float(g2.item()), 3) if g2 is not None else None,
+                        "bytes_into_rank0_per_step": inbound,
                         "inbound_GBps_serial": round(inbound / (float(g1.item()) * 1e-3) / 1e9, 2) if inbound else 0.0}
     vctx = lanes[state.get("last_lane", 0)]["ctx"] if (not multi) else (mctx[state.get("last_buf", 0)] if pipe is None else ctx)   # the context of the last step
     bad, first_bad = vctx.verify_last()
@@ -510,6 +538,42 @@ def main():
             del dst6, ctx6
         except Exception as e:
             extra["level6"] = {"error": str(e)}
+
+        # The reference's threaded=false form (zzflate.cpp:84-95: ONE Encoder over the whole input, what all of its own tests
+        # call) is one dependency chain per call, so it runs on one wavefront: a compatibility mode. Its rate, stated: one call
+        # of 64 MiB at levels 1 and 2, and 64 concurrent callers of 1 MiB each (64 contexts, 64 host threads) to show that
+        # independent callers scale over the CUs.
+        try:
+            import threading
+            seq = {}
+            nseq = min(n, 64 << 20)
+            capq = max(zz.bound(nseq, fmt, 2, P), 2 * nseq)
+            dstq = torch.empty(capq, dtype=torch.uint8, device="cuda")
+            for lvl in (1, 2):
+                ctx.encode_stream(src, 1 << 20, dstq, capq, fmt, lvl)
+                torch.cuda.synchronize(); tq = time.perf_counter()
+                wq = ctx.encode_stream(src, nseq, dstq, capq, fmt, lvl)
+                torch.cuda.synchronize(); dq = time.perf_counter() - tq
+                seq[f"level{lvl}_one_call"] = {"value": round(nseq / dq / 1e9, 4), "unit": "GB/s", "bytes": nseq, "ratio": round(wq / nseq, 4)}
+            K, piece = 64, 1 << 20
+            ctxs = [zz.Context(dev) for _ in range(K)]
+            outs = [torch.empty(2 * piece + 4096, dtype=torch.uint8, device="cuda") for _ in range(K)]
+            strs = [torch.cuda.Stream(device=dev) for _ in range(K)]
+            def one(i, lvl):
+                ctxs[i].encode_stream(src[i * piece:(i + 1) * piece], piece, outs[i], 2 * piece + 4096, fmt, lvl, stream=strs[i].cuda_stream)
+            for lvl in (1, 2):
+                for rep in range(2):             # (the first round allocates the contexts' workspaces)
+                    torch.cuda.synchronize(); tq = time.perf_counter()
+                    th = [threading.Thread(target=one, args=(i, lvl)) for i in range(K)]
+                    for t_ in th: t_.start()
+                    for t_ in th: t_.join()
+                    torch.cuda.synchronize(); dq = time.perf_counter() - tq
+                seq[f"level{lvl}_64_callers_of_1MiB"] = {"value": round(K * piece / dq / 1e9, 4), "unit": "GB/s"}
+            seq["note"] = "threaded=false (the reference's single Encoder): one wavefront per call, a compatibility mode; packet mode (threaded=true) is `value`"
+            extra["sequential"] = seq
+            del ctxs, outs, dstq
+        except Exception as e:
+            extra["sequential"] = {"error": str(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:        # (the CPU leg runs at N = 1 only: the other ranks would wait for it)

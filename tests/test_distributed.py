@@ -55,6 +55,12 @@ def _worker(rank, world, port, fname, fmt, lvl, P, result_path, chunks=1):
         if rank == 0:
             assert t1 == total and bytes(outbuf2[:t1].numpy()) == bytes(outbuf[:total].numpy())
         assert sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf) == total
+        # a rotating gather root (bench.py --gather-root rotate: stream i onto rank i mod N): the same stream assembled on rank 1
+        outbuf_r = torch.zeros(2 * len(data) + 4096, dtype=torch.uint8) if rank == 1 else None
+        tr = sharded.gather_stream(dist, fmt, shard, len(out), cks, n, outbuf_r, root=1)
+        rot_ok = torch.tensor([1 if (rank != 1 or (tr == total and outbuf_r[:tr].numpy().tobytes() == oracle.encode_packets(data, fmt, lvl, P))) else 0])
+        dist.all_reduce(rot_ok, op=dist.ReduceOp.MIN)
+        assert int(rot_ok.item()) == 1 and tr == total
     else:
         # pipelined variant: the shard leaves in `chunks` packet-aligned pieces
         pg = sharded.PipelinedGather(dist, fmt, 2 * len(data) + 4096, torch.device("cpu"))

@@ -146,6 +146,15 @@ def test_bench_launches_its_own_ranks(tmp_path):
     l2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert l2["n_gpus"] == 2 and l2["exchange"] is None and "nothing exchanged" in l2["config"]["workload"]
     assert l2["check"]["device_inflate"]["bad"] == 0 and l2["check"]["inflate_prefix_ok"]
+    # --gather-root rotate: step i's stream lands on rank i mod 2 (three steps: both ranks take a turn); the line, the
+    # device inflate of every packet and the zlib check of the stream on rank 0 must come out the same
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--mib", "64",
+                         "--no-cpu", "--no-extra", "--gather-root", "rotate"], env=env, capture_output=True, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    l3 = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
+    assert l3["n_gpus"] == 2 and l3["ratio"] == line["ratio"] and l3["exchange"]["gather_root"] == "rotate"
+    assert l3["exchange"]["gather_ms_serial_onto_last_rank"] > 0
+    assert l3["check"]["device_inflate"]["bad"] == 0 and l3["check"]["inflate_prefix_ok"]
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

@@ -696,9 +696,11 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, d_dst, cap, format, c->d_cks_total, n, c->d_res);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(zz_result), hipMemcpyDeviceToHost, st));
-    uint32_t kerr[4] = { 0, 0, 0, 0 };
-    HIPCHK(hipMemcpyAsync(kerr, c->d_err, sizeof kerr, hipMemcpyDeviceToHost, st));
+    // (into pinned memory: an asynchronous copy into pageable memory is staged by the runtime and makes concurrent callers on
+    // other streams take turns)
+    HIPCHK(hipMemcpyAsync(c->h_err, c->d_err, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const uint32_t kerr[4] = { c->h_err[0], c->h_err[1], c->h_err[2], c->h_err[3] };
     *host_res = *c->h_res;
     if (kerr[0]) { set_err("internal: output slot overflow"); return ZZ_E_NOSPACE; }
     if (kerr[1]) {

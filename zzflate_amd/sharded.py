@@ -4,9 +4,11 @@ std::async fan-out + memmove join, zzflate.cpp:97-155, across devices).
 Packets are independent and every non-final packet ends byte-aligned, so ranks own contiguous packet ranges
 and the shard outputs concatenate by plain byte copy. The only exchange is
   1. an all-gather of (compressed bytes, checksum partial, input bytes) per rank, and
-  2. ONE gather of the variable-size compressed shards onto rank 0, as a grouped send/recv (RCCL has no
+  2. ONE gather of the variable-size compressed shards onto the stream's root rank, as a grouped send/recv (RCCL has no
      gatherv); compressed bytes travel, never input bytes.
-Rank 0 then adds the container header and the trailer from the combined checksums.
+The root then adds the container header and the trailer from the combined checksums. The root is rank 0 unless the caller
+names another: a job that produces stream after stream can rotate it (stream i onto rank i mod N), so that successive
+streams do not all arrive over ONE GPU's seven inbound xGMI links while the other GPUs' inbound links idle.
 
 Backend-agnostic: `nccl` (= RCCL over xGMI) with device tensors in bench.py, `gloo` with CPU tensors in the
 tests. The per-shard encoder is whatever the caller ran (Context.encode_shard on a GPU).
@@ -54,12 +56,13 @@ class _Pending:
         return self.total
 
 
-def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None, wait=True):
+def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None, wait=True, root=0):
     """Collective. `shard[:shard_bytes]` is this rank's compressed shard (uint8 tensor), `cks` its checksum
-    partial, `n_in` its input byte count. On rank 0 returns the total stream length written into `out`
-    (header + shards + trailer); elsewhere returns None. With wait=False the grouped send/recv is left in flight and
-    a handle comes back instead (`.wait()` -> the same result): the caller encodes its next stream into other
-    buffers meanwhile, so the transfer over xGMI hides behind compute."""
+    partial, `n_in` its input byte count. Returns the total stream length (header + shards + trailer) on every rank -- it
+    follows from the all-gathered sizes --; the bytes are written into `out` on rank `root` only (the other ranks pass
+    out=None). With wait=False the grouped send/recv is left in flight and a handle comes back instead (`.wait()` -> the
+    same result): the caller encodes its next stream into other buffers meanwhile, so the transfer over xGMI hides behind
+    compute."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = shard.device
     meta = torch.tensor([shard_bytes, cks, n_in], dtype=torch.int64, device=dev)
@@ -73,23 +76,22 @@ def gather_stream(dist, fmt, shard, shard_bytes, cks, n_in, out=None, group=None
     for r in range(world):
         offs.append(off)
         off += sizes[r]
-    if rank == 0:
-        assert out is not None and out.numel() >= off + 8, "rank 0 needs an output buffer"
-        for r in range(1, world):
-            if sizes[r]:
+    if rank == root:
+        assert out is not None and out.numel() >= off + 8, "the root rank needs an output buffer"
+        for r in range(world):
+            if r != root and sizes[r]:
                 ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r] + sizes[r]], r, group))
-        out[offs[0]:offs[0] + sizes[0]].copy_(shard[:sizes[0]])
+        out[offs[root]:offs[root] + sizes[root]].copy_(shard[:sizes[root]])
     elif sizes[rank]:
-        ops.append(dist.P2POp(dist.isend, shard[:sizes[rank]], 0, group))
+        ops.append(dist.P2POp(dist.isend, shard[:sizes[rank]], root, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    total = None
-    if rank == 0:
-        tail = trailer(fmt, combine_checksums(fmt, list(zip(ckss, lens))), sum(lens))
+    tail = trailer(fmt, combine_checksums(fmt, list(zip(ckss, lens))), sum(lens))
+    if rank == root:
         if head:
             out[:len(head)].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
         if tail:
             out[off:off + len(tail)].copy_(torch.frombuffer(bytearray(tail), dtype=torch.uint8))
-        total = off + len(tail)
+    total = off + len(tail)
     pending = _Pending(reqs, total, (shard, out))
     return pending.wait() if wait else pending
 
