@@ -197,6 +197,7 @@ def main():
                     "streams is not capped by ONE GPU's seven inbound xGMI links")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
+    ap.add_argument("--no-sequential", action="store_true", help="skip the threaded=false side measurement (64 MiB on one wavefront: seconds)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -544,6 +545,8 @@ def main():
         # of 64 MiB at levels 1 and 2, and 64 concurrent callers of 1 MiB each (64 contexts, 64 host threads) to show that
         # independent callers scale over the CUs.
         try:
+            if args.no_sequential:
+                raise RuntimeError("skipped (--no-sequential)")
             import threading
             seq = {}
             nseq = min(n, 64 << 20)

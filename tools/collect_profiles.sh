@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu"
+B="python3 $R/bench.py --no-cpu --no-sequential"
 run() { name=$1; shift; echo "[collect] $name"; timeout -k 10 280 rocprofv3 "$@" > "$OUT/$name.log" 2>&1; }
 run stats_l1  --kernel-trace --stats --output-format csv -d "$OUT/stats_l1" -- $B --steps 5 --warmup 1
 run fetch_l1  --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_l1" -- $B --steps 2 --warmup 1

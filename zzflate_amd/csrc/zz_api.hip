@@ -486,6 +486,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             hipLaunchKernelGGL(k_encode_l0, dim3(g), dim3(256), 0, st, q);
             hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, (uint8_t*)nullptr, 0ull, 0u, c->d_res, total);
         } else if (level == 1) {
+            hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);      // (what reads past the shard's end reads this)
             // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
             // ZZFLATE_L1_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet (k_encode_l1) instead of the two of
@@ -493,11 +494,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             static const bool classic = [] { const char* e = getenv("ZZFLATE_L1_KERNEL"); return e && !strcmp(e, "classic"); }();
             if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
             else if (classic || !lds_order_ok(c->device)) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
-            else {
-                hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);
-                hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
-            }
+            else hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
         } else {
+            hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);
             launch_level2(pp, c->l2_scratch, c->d_work, st, xdepth);
         }
         if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }

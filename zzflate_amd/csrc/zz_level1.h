@@ -119,6 +119,55 @@ __device__ __forceinline__ uint32_t calc_hash3(uint32_t three_bytes)   // encode
     return ((three_bytes & 0xFFFFFFu) * 0x00d68664u) >> (32 - ZZ_HASH_BITS);
 }
 
+// Loads that may run past the shard's last byte (only a shard's last packet has any, and only in its last blocks) are turned to
+// a 128-byte copy of the shard's end that the host keeps behind it: its last 64 bytes, then zeros (zz_packet_params::tail, filled
+// by k_fill_tail before the launch). One compare and one select per load, where bounds-checked byte-wise loads (load64_safe)
+// cost the kernel its register budget: 65 VGPRs and 100 SGPRs with them, 62 and 62 without.
+struct l1p_src {
+    const uint8_t* src;        // the packet's first byte
+    const uint8_t* tailp;      // tail copy, biased: tailp + position = the copy's byte for that position
+    int32_t lim;               // positions above this one (packet-relative) read from the copy: shard end - 16
+};
+// (positions are packet-relative and may be negative: a candidate in the window in front of the packet, levels >= 2)
+template <bool TAIL> __device__ __forceinline__ const uint8_t* l1p_addr(const l1p_src& S, int32_t pos)
+{
+    if (!TAIL) return S.src + pos;
+    return (pos > S.lim ? S.tailp : S.src) + pos;
+}
+// src: the packet's first byte; end: one past the shard's last readable byte (P.src + P.n); the copy starts at
+// max(shard end - 64, shard start) (k_fill_tail)
+__device__ __forceinline__ l1p_src l1p_make_src(const zz_packet_params& P, const uint8_t* src, const uint8_t* end)
+{
+    l1p_src S;
+    const int64_t endrel = (int64_t)(end - src);
+    const uint64_t tn = P.n < 64 ? P.n : 64;
+    S.src = src;
+    S.lim = endrel - 16 > 0x7fffffff ? 0x7fffffff : (int32_t)(endrel - 16);
+    S.tailp = P.tail - (endrel - (int64_t)tn);
+    return S;
+}
+template <bool TAIL> __device__ __forceinline__ void l1p_ld128(const l1p_src& S, int32_t pos, uint64_t& lo, uint64_t& hi)
+{
+    uint4 v;
+    __builtin_memcpy(&v, l1p_addr<TAIL>(S, pos), 16);
+    lo = ((uint64_t)v.y << 32) | v.x;
+    hi = ((uint64_t)v.w << 32) | v.z;
+}
+// wave_extend_match (zz_level1.h) over these loads
+__device__ __forceinline__ uint32_t l1p_extend_match(const l1p_src& S, uint32_t pe, int32_t cand, uint32_t maxlen, uint32_t from = 8)
+{
+    const uint32_t o = from + 4 * (uint32_t)lane_id();
+    uint32_t d = 0;
+    const bool act = o < maxlen;
+    if (act) d = load32(l1p_addr<true>(S, (int32_t)(pe + o))) ^ load32(l1p_addr<true>(S, cand + (int32_t)o));
+    const uint64_t neq = ballot(act && d != 0);
+    if (!neq) return maxlen;
+    const int k = __builtin_ctzll(neq);
+    const uint32_t dk = readlane(d, k);
+    const uint32_t len = from + 4 * (uint32_t)k + ((uint32_t)__builtin_ctz(dk) >> 3);
+    return len < maxlen ? len : maxlen;
+}
+
 // per-lane walk info, packed into one VGPR so that the scalar walk needs a single v_readlane per event. The match
 // length against the table candidate sits in bits 0..5 (bit 5 always clear) because s_bfm_b64 takes its field size from
 // exactly those bits of its operand: the walk never has to extract it.

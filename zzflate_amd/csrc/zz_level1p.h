@@ -61,42 +61,6 @@ struct l1p_xch {
 };   // 336 bytes
 
 
-// Loads that may run past the shard's last byte (only a shard's last packet has any, and only in its last blocks) are turned to
-// a 128-byte copy of the shard's end that the host keeps behind it: its last 64 bytes, then zeros (zz_packet_params::tail, filled
-// by k_fill_tail before the launch). One compare and one select per load, where bounds-checked byte-wise loads (load64_safe)
-// cost the kernel its register budget: 65 VGPRs and 100 SGPRs with them, 62 and 62 without.
-struct l1p_src {
-    const uint8_t* src;        // the packet's first byte
-    const uint8_t* tailp;      // tail copy, biased: tailp + position = the copy's byte for that position
-    int32_t lim;               // positions above this one (packet-relative) read from the copy: shard end - 16
-};
-template <bool TAIL> __device__ __forceinline__ const uint8_t* l1p_addr(const l1p_src& S, uint32_t pos)
-{
-    if (!TAIL) return S.src + pos;
-    return ((int32_t)pos > S.lim ? S.tailp : S.src) + pos;
-}
-template <bool TAIL> __device__ __forceinline__ void l1p_ld128(const l1p_src& S, uint32_t pos, uint64_t& lo, uint64_t& hi)
-{
-    uint4 v;
-    __builtin_memcpy(&v, l1p_addr<TAIL>(S, pos), 16);
-    lo = ((uint64_t)v.y << 32) | v.x;
-    hi = ((uint64_t)v.w << 32) | v.z;
-}
-// wave_extend_match (zz_level1.h) over these loads
-__device__ __forceinline__ uint32_t l1p_extend_match(const l1p_src& S, uint32_t pe, uint32_t cand, uint32_t maxlen, uint32_t from = 8)
-{
-    const uint32_t o = from + 4 * (uint32_t)lane_id();
-    uint32_t d = 0;
-    const bool act = o < maxlen;
-    if (act) d = load32(l1p_addr<true>(S, pe + o)) ^ load32(l1p_addr<true>(S, cand + o));
-    const uint64_t neq = ballot(act && d != 0);
-    if (!neq) return maxlen;
-    const int k = __builtin_ctzll(neq);
-    const uint32_t dk = readlane(d, k);
-    const uint32_t len = from + 4 * (uint32_t)k + ((uint32_t)__builtin_ctz(dk) >> 3);
-    return len < maxlen ? len : maxlen;
-}
-
 // One parsing wavefront (pw = 0: even blocks, 1: odd blocks). Barriers: B_g closes the walk of block g - 1. Per block g its
 // owner runs  [P1 P2](g)  B_g  [R W](g)  B_g+1  [P4](g)  and then block g + 2; the other wavefront is one barrier out of step.
 __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk& pk, uint16_t* T, uint32_t* tokbuf, l1p_xch* X, const uint32_t pw)
@@ -104,15 +68,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     const int lane = lane_id();
     const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
     const uint32_t n = pk.n;
-    l1p_src SRC;
-    {
-        // shard end relative to the packet's first byte; the copy starts at max(shard end - 64, shard start) (k_fill_tail)
-        const int64_t endrel = (int64_t)(pk.end - pk.src);
-        const uint64_t tn = P.n < 64 ? P.n : 64;
-        SRC.src = pk.src;
-        SRC.lim = endrel - 16 > 0x7fffffff ? 0x7fffffff : (int32_t)(endrel - 16);
-        SRC.tailp = P.tail - (endrel - (int64_t)tn);
-    }
+    const l1p_src SRC = l1p_make_src(P, pk.src, pk.end);
     const uint32_t NB = (n + ZZ_WAVE - 1) >> 6;                          // blocks of the packet, n > 0
     lds_u32* const slot = (lds_u32*)tokbuf + lane + pw * ZZ_L1_TOKSLOT;   // block g's tokens go to slot g & 1
     uint64_t w = 0, w2 = 0;                                               // 16 bytes at this lane's position of the block at hand
@@ -291,7 +247,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     if (mlen >= 4) {
                         if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
                             const uint32_t cand = useB ? base + ZZ_WI_QLANE(inf) : readlane(told, e) - 1;
-                            mlen = l1p_extend_match(SRC, pe, cand, maxlen, ZZ_WI_CAP);
+                            mlen = l1p_extend_match(SRC, pe, (int32_t)cand, maxlen, ZZ_WI_CAP);
                             if (lane == e) ovlen = mlen | 0x8000u;
                             ovmL |= 1ull << e;
                         }
@@ -315,7 +271,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     mlen = 0;
                     if ((uint32_t)xe == 0 && maxlen >= 4) {
                         if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
-                        else mlen = l1p_extend_match(SRC, pe, cand1 - 1, maxlen);
+                        else mlen = l1p_extend_match(SRC, pe, (int32_t)(cand1 - 1), maxlen);
                         if (mlen > maxlen) mlen = maxlen;
                     }
                     if (lane == e) { ovlen = mlen | 0x8000u; ovcand1 = cand1; }

@@ -548,8 +548,11 @@ __device__ __forceinline__ uint32_t sub_from4_sat(uint32_t v)           // max(4
     return r;
 }
 
-template <bool SAFE, uint32_t BIAS = 0>
-__device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const uint8_t* src, const uint8_t* end,
+// TS: the same bytes as `src`, with loads that would leave the shard turned to the copy of its end (l1p_src, zz_level1p.h):
+// one instance of this function instead of a second, bounds-checked one -- that one's byte-wise loads cost the kernel 18
+// spilled VGPRs (76 bytes of scratch per lane until round 4).
+template <uint32_t BIAS = 0>
+__device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const uint8_t* src, const uint8_t* end, const l1p_src& TS,
                                               uint32_t n, uint64_t before, unsigned long long* prof = nullptr)
 {
     const int lane = lane_id();
@@ -568,7 +571,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
     // this lane's own bytes: 16 from its position (hash + forward compare) and the 8 in front (backward compare)
     uint64_t wa = 0, wa2 = 0, wb = 0;
     if ((uint32_t)lane < n) {
-        ld128<SAFE>(src + lane, end, wa, wa2);
+        l1p_ld128<true>(TS, lane, wa, wa2);
         if (before + (uint32_t)lane >= 8) wb = load64(src + (int64_t)lane - 8);
     }
     uint32_t slotsel = 0;           // word offset of the hand-over slot in use (alternates)
@@ -775,7 +778,7 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 uint32_t bw = bre < pe ? bre : pe;
                 {
                     const int32_t ce = (int32_t)readlane((uint32_t)c, e);
-                    if (fwd == 16) fwd = wave_extend_match<SAFE>(src, qe, ce, ZZ_MAX_LEN, end, 16);    // remain(), :64-90
+                    if (fwd == 16) fwd = l1p_extend_match(TS, qe, ce, ZZ_MAX_LEN, 16);    // remain(), :64-90
                     const uint32_t re = readlane(room, e);
                     const uint32_t blim = re < pe ? re : pe;
                     if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
@@ -1112,8 +1115,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
                 // the extended levels: every position's match is in Q.m already (k_l6_matches, zz_level6.h)
                 if (W0) {
                     const uint32_t* mrow = Q.m + (uint64_t)(k - Q.k0) * P.packet_size;
-                    if (off + len + 16 > P.n) l6_parse_pass<true>(hb, src, end, n, mrow);
-                    else l6_parse_pass<false>(hb, src, end, n, mrow);
+                    l6_parse_pass(hb, src, end, l1p_make_src(P, src, end), n, mrow);
                 }
             } else if (W0) {
                 if (BIAS) {
@@ -1123,8 +1125,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
                 }
                 // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
-                if (off + len + 16 > P.n) l2_token_pass<true, BIAS>(T, hb, src, end, n, before, P.prof);
-                else l2_token_pass<false, BIAS>(T, hb, src, end, n, before, P.prof);
+                l2_token_pass<BIAS>(T, hb, src, end, l1p_make_src(P, src, end), n, before, P.prof);
             }
             if (!W0) {
                 uint32_t nb = 0, adA = 0;

@@ -346,8 +346,7 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
 
 // ===== kernel 2's parser: the greedy parse over those words; hands every block's matches to the helper wavefront in the
 // level-2 format (zz_level2.h: ZZ_L2_HB_PACK, one s_barrier per block) =========================================================
-template <bool SAFE>
-__device__ __forceinline__ void l6_parse_pass(uint32_t* hb, const uint8_t* src, const uint8_t* end, uint32_t n, const uint32_t* mrow)
+__device__ __forceinline__ void l6_parse_pass(uint32_t* hb, const uint8_t* src, const uint8_t* end, const l1p_src& TS, uint32_t n, const uint32_t* mrow)
 {
     const int lane = lane_id();
     const uint32_t target = l6_target(n);
@@ -378,7 +377,7 @@ __device__ __forceinline__ void l6_parse_pass(uint32_t* hb, const uint8_t* src, 
             if (len == ZZ_L6_CAP) {
                 const uint32_t qe = base + (uint32_t)e;
                 const uint32_t maxlen = (n - qe) < ZZ_MAX_LEN ? (n - qe) : ZZ_MAX_LEN;
-                len = wave_extend_match<SAFE>(src, qe, (int32_t)(qe - readlane(bdist, e)), maxlen, end, ZZ_L6_CAP);   // (4-byte loads: may look 3 bytes past n)
+                len = l1p_extend_match(TS, qe, (int32_t)(qe - readlane(bdist, e)), maxlen, ZZ_L6_CAP);   // (4-byte loads: may look 3 bytes past n)
                 if (lane == e) tlen = len;
             }
             evmask |= 1ull << e;
