@@ -650,7 +650,7 @@ def main():
             "exchange": exchange if multi else None,
             "roofline": {
                 "bound": "hbm", "kernel": ("k_l6_matches + k_encode_l2_t" if args.level >= 4 else "k_encode_l2_t" if args.level >= 2
-                                           else f"k_encode_l{args.level}"),
+                                           else ("k_encode_l1w" if args.warm else "k_encode_l1p") if args.level == 1 else "k_encode_l0"),
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4), "traffic": traffic,
