@@ -94,6 +94,13 @@ __device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t v)
     asm("v_ffbl_b32_e32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
+// v_ffbh_u32: the number of leading zero bits, and -1 (not 32) for 0
+__device__ __forceinline__ uint32_t ffbh_or_ones(uint32_t v)
+{
+    uint32_t r;
+    asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 template <int K> __device__ __forceinline__ uint32_t add_sat_k(uint32_t v)
 {
     uint32_t r;
@@ -150,6 +157,16 @@ template <bool TAIL> __device__ __forceinline__ void l1p_ld128(const l1p_src& S,
 {
     uint4 v;
     __builtin_memcpy(&v, l1p_addr<TAIL>(S, pos), 16);
+    lo = ((uint64_t)v.y << 32) | v.x;
+    hi = ((uint64_t)v.w << 32) | v.z;
+}
+// the same for a position that is known not to be negative (an unsigned offset from the uniform base is the load's own
+// addressing mode; a signed one costs a sign extension and a 64-bit addition in front of it)
+template <bool TAIL> __device__ __forceinline__ void l1p_ld128u(const l1p_src& S, uint32_t pos, uint64_t& lo, uint64_t& hi)
+{
+    uint4 v;
+    if (TAIL) __builtin_memcpy(&v, l1p_addr<true>(S, (int32_t)pos), 16);
+    else __builtin_memcpy(&v, S.src + pos, 16);
     lo = ((uint64_t)v.y << 32) | v.x;
     hi = ((uint64_t)v.w << 32) | v.z;
 }

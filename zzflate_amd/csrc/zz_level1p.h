@@ -52,13 +52,19 @@ namespace zz {
 #ifndef ZZ_L1P_PRIO_E
 #define ZZ_L1P_PRIO_E 0         // ... and of the emitter
 #endif
+#ifndef ZZ_L1P_R2
+#define ZZ_L1P_R2 1             // 1: the short form of R (sentinel slot for lanes that are not cross lanes, "none" = 64); 0: the round's first form
+#endif
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
+#define ZZ_L1P_NONE 64u          // win[]: no lane of the block with that hash was visited
+#define ZZ_L1P_SELF 65u          // the slot lanes that are NOT cross lanes read: win[65] = 65, "my candidate is the one I read"
 struct l1p_xch {
-    uint32_t told[ZZ_WAVE];        // per lane of block t - 1, t = the word's high half: the table's entry under the lane's hash BEFORE that block
-    uint8_t win[ZZ_WAVE];          // per lane of the block walked last: the highest VISITED lane of the block with the lane's hash, 0x80 = none
+    uint32_t told[ZZ_WAVE + 4];    // per lane of block t - 1, t = the word's high half: the table's entry under the lane's hash BEFORE that block
+    uint8_t win[ZZ_WAVE + 4];      // per lane of the block walked last: the highest VISITED lane of the block with the lane's hash, 64 = none; [65] = 65
     uint32_t scal[4];              // [0]: the positions by which the block walked last runs into the next one
-};   // 336 bytes
+};   // 356 bytes
+
 
 
 // One parsing wavefront (pw = 0: even blocks, 1: odd blocks). Barriers: B_g closes the walk of block g - 1. Per block g its
@@ -66,7 +72,7 @@ struct l1p_xch {
 __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk& pk, uint16_t* T, uint32_t* tokbuf, l1p_xch* X, const uint32_t pw)
 {
     const int lane = lane_id();
-    const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
+    const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1), self_bit = 1ull << lane;
     const uint32_t n = pk.n;
     const l1p_src SRC = l1p_make_src(P, pk.src, pk.end);
     const uint32_t NB = (n + ZZ_WAVE - 1) >> 6;                          // blocks of the packet, n > 0
@@ -93,7 +99,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             l1_group_barrier();                                          // B_g
             const uint32_t cin = uniform(X->scal[0]);                    // (>= 64: the block in front was covered too)
             mycout = cin > ZZ_WAVE ? cin - ZZ_WAVE : 0u;
-            X->win[lane] = 0x80;
+            X->win[lane] = ZZ_L1P_R2 ? (uint8_t)ZZ_L1P_NONE : (uint8_t)0x80;
             X->told[lane] = (g + 1) << 16;
             if (lane == 0) X->scal[0] = mycout;
             l1_group_barrier();                                          // B_g+1
@@ -120,7 +126,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint64_t wn = 0, wn2 = 0;                                    // this lane's bytes two blocks on: blocks are fixed, so the address is known
             if (g + 2 < NB) {
                 const uint32_t pn = p + 2 * ZZ_WAVE;
-                l1p_ld128<!INT>(SRC, INT ? pn : (pn < n ? pn : n - 1), wn, wn2);
+                l1p_ld128u<!INT>(SRC, INT ? pn : (pn < n ? pn : n - 1), wn, wn2);
             }
             ZZ_WAVE_SYNC();
             const uint32_t rb = T[h];                                    // the slot holds whichever lane wrote last
@@ -135,15 +141,23 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
 #endif
             uint32_t talt = 0;
             uint64_t wa = 0, wa2 = 0;
-            const uint32_t qa = xd ? qx : 0u;
+            // (lanes that are not cross lanes point at the sentinel slot: what they read there says "the candidate as read")
+            const uint32_t qa = xd ? qx : (ZZ_L1P_R2 ? ZZ_L1P_SELF : 0u);
             if (XD) {
                 // what the table held under this hash BEFORE block g - 1: its owner publishes that, tagged with the block, as soon as
                 // it has settled its own cross lanes (right after B_g-1; this wavefront has repaired block g - 2 since)
                 uint32_t v;
+#if ZZ_L1P_R2
+                do {
+                    ZZ_C(13, 1);
+                    v = *(volatile lds_u32*)&X->told[qa];
+                } while (ballot((v >> 16) != g) & XD);                   // (the scalar AND of two masks: no select, no second compare)
+#else
                 do {
                     ZZ_C(13, 1);
                     v = *(volatile lds_u32*)&X->told[qa];
                 } while (ballot(xd && (v >> 16) != g));
+#endif
                 talt = xd ? (v & 0xFFFFu) : 0u;
                 if (xd) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(talt, 1u), wa, wa2);      // (a gather costs the address path per lane)
             }
@@ -152,7 +166,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             const uint64_t lostmask = ballot(active && rb != (uint32_t)(uint16_t)(p + 1));
             const uint32_t left = active ? n - p : 0;
             const uint32_t cap17 = INT ? 8u * (ZZ_WI_CAP + 1) : (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;
-            uint64_t myset = 0;
+            uint64_t myset = ZZ_L1P_R2 ? self_bit : 0;                   // the lanes of the block with my hash, myself included
             uint32_t infoB = 0;
             if (lostmask) {
                 uint32_t W = (uint32_t)lane;
@@ -181,6 +195,47 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint32_t cin;
             uint32_t told, info;
             uint64_t x;                                                  // the candidate's first eight bytes XOR mine
+#if ZZ_L1P_R2
+            {
+                // Everything between the barrier and the walk is on the packet's critical path, instruction by instruction. Both
+                // reads go out at once and unconditionally: a lane that is not a cross lane reads the sentinel (win[65] = 65 = its
+                // qa), and "what I read is my qa" means "the candidate is the table's entry as read" -- for it as for a cross lane
+                // whose q the walk visited (q is the highest lane of its set: the LDS leaves the highest lane's store in the slot).
+                // Otherwise: 64 = nobody with my hash was visited, the entry from before the block; a lower lane r: its bytes are not here.
+                const uint32_t sc = X->scal[0];
+                const uint32_t r = X->win[qa];
+                const bool moved = r != qa;
+                const bool use3 = r == ZZ_L1P_NONE;
+                const uint32_t toldh = (base - ZZ_WAVE + 1u) + r;
+                const uint32_t t1 = use3 ? talt : toldh;
+                told = moved ? t1 : oldraw;
+                // the block behind is waiting for this (its cross lanes' second candidate): out first
+                X->told[lane] = told | ((g + 1) << 16);
+                const uint64_t LDM = ballot(moved) & ~ballot(use3);
+                uint64_t l0 = 0, l1 = 0;
+                if (LDM) {
+                    ZZ_C(14, 1);
+                    // a lower lane of block g - 1: its bytes come from the cache (that block's owner has just read them); asked for
+                    // before anything else so that the comparison below runs under the load (every lane loads: no lane mask to set
+                    // up; the others read their own candidate's line again) -- 0.2 times per block of text, 0.35 of the mix
+                    l1p_ld128u<!INT>(SRC, __builtin_elementwise_sub_sat(told, 1u), l0, l1);
+                }
+                __builtin_amdgcn_sched_barrier(0);                       // (nothing that waits for the candidates' bytes may move in front of that)
+                cin = uniform(sc);
+                const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
+                x = w ^ c;
+                uint32_t la = equal_bits128(x, w2 ^ c2, cap17) >> 3;
+                if (!told) la = 0;
+                info = infoB | (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la);
+                if (LDM) {
+                    const uint64_t x3 = w ^ l0;
+                    const uint32_t la3 = equal_bits128(x3, w2 ^ l1, cap17) >> 3;
+                    const uint32_t info3 = infoB | (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3);
+                    x = ((uint64_t)sel_lanes(LDM, (uint32_t)(x3 >> 32), (uint32_t)(x >> 32)) << 32) | sel_lanes(LDM, (uint32_t)x3, (uint32_t)x);
+                    info = sel_lanes(LDM, info3, info);
+                }
+            }
+#else
             {
                 const uint32_t sc = X->scal[0];
                 const uint32_t r = XD ? X->win[qa] : 0u;                 // the highest visited lane of block g - 1 with my hash (0x80: none)
@@ -214,6 +269,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     }
                 }
             }
+#endif
             const uint64_t E = ballot((info & (ZZ_WI_HARD | 0x1Cu | (0x1Cu << ZZ_WI_LENB_SHIFT))) != 0);
             {
                 const uint32_t endl = (uint32_t)lane + (info & 31u);
@@ -296,8 +352,15 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             }
             {
                 // for the block behind: per lane the highest visited lane with its hash; the match end carried over
+#if ZZ_L1P_R2
+                // (v_ffbh gives -1 for 0 and the addition saturates: 63 - min is 64 = "none" by itself, no compare, no select)
+                const uint64_t sv = myset & committed;
+                const uint32_t fh = ffbh_or_ones((uint32_t)(sv >> 32)), fl = add_sat_k<32>(ffbh_or_ones((uint32_t)sv));
+                X->win[lane] = (uint8_t)(63u - (fh < fl ? fh : fl));
+#else
                 const uint64_t sv = (myset | (1ull << lane)) & committed;
                 X->win[lane] = (uint8_t)(sv ? 63u - (uint32_t)__builtin_clzll(sv) : 0x80u);
+#endif
                 mycout = pos > ZZ_WAVE ? pos - ZZ_WAVE : 0u;
                 if (lane == 0) X->scal[0] = mycout;
             }
@@ -355,6 +418,7 @@ __device__ __forceinline__ void l1p_packet_parser(const zz_packet_params& P, uin
     for (int i = lane; i < (int)(ZZ_HASH_SIZE * sizeof(uint16_t) / 32); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
     if (pw == 0 && lane < 4) X->scal[lane] = 0;                          // block 0: nothing carried in
     if (pw == 0) X->told[lane] = 0;                                      // (tag 0: no block's)
+    if (pw == 1 && lane == 0) X->win[ZZ_L1P_SELF] = (uint8_t)ZZ_L1P_SELF; // the sentinel (zz_level1p.h, R)
     l1_group_barrier();                                                  // B_z
     if (q.n > 0) {
         l1p_parse(P, q, T, tokbuf, X, pw);
@@ -383,6 +447,9 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
             l1_group_barrier();                                          // B_g+2: block g's tokens are in slot g & 1
             const uint32_t tok = *slot;
             slot = lds_flip_slot((lds_u32*)slot);
+#ifdef ZZ_L1P_X_NOEMIT
+            if (g == 0)                                                  // TIMING EXPERIMENT: the emitter only keeps the barriers (wrong streams)
+#endif
             l1_emit_tokens(ring, nullptr, tok);
         }
         ring_append_uniform(ring, 0, 7);                                 // EOB: codes_f[256] (encoder.cpp:371)

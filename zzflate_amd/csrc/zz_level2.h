@@ -534,13 +534,7 @@ __device__ __forceinline__ uint32_t l2_probe_blocks(uint32_t n)     // trips of 
 // BIAS = 32768: warm window (the extended levels 4..6, see zz_api.hip): table entries are position + 1 + BIAS, the
 // positions -32768 .. -1 in front of the packet were hashed into the table by the caller; candidates 32768 or more back
 // are ignored (encoder.cpp:392).
-// ffbh with the same "-1 for 0" as ffbl_or_ones, for equal TRAILING bytes (the bytes in front of a position)
-__device__ __forceinline__ uint32_t ffbh_or_ones(uint32_t v)
-{
-    uint32_t r;
-    asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
+// (ffbh_or_ones, zz_level1.h: "-1 for 0" as ffbl_or_ones has it, here for equal TRAILING bytes, the bytes in front of a position)
 __device__ __forceinline__ uint32_t sub_from4_sat(uint32_t v)           // max(4 - v, 0)
 {
     uint32_t r;
