@@ -246,6 +246,11 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
     int32_t e, e2;
     uint32_t inf, len, q, t0, vt;
 #define ZZ_L1_WALK_BODY \
+        "1:\n\t"                                    /* (pos < 64 here) */ \
+        "s_lshl_b64 %[tmp], -1, %[pos]\n\t" \
+        "s_and_b64 %[tmp], %[tmp], %[E]\n\t"        /* events at or after pos; SCC = there is one */ \
+        "s_cbranch_scc0 30f\n\t" \
+        "s_ff1_i32_b64 %[e], %[tmp]\n"              /* the first of them: straight into the hop loop */ \
         "9:\n\t" \
         ZZ_L1_HOP("%[e]", "%[e2]", "4f") "s_cbranch_scc0 31f\n\t" \
         ZZ_L1_HOP("%[e2]", "%[e]", "41f") "s_cbranch_scc1 9b\n\t" \
@@ -264,14 +269,8 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_or_b64 %[cov], %[cov], %[tmp]\n\t" \
         "s_add_u32 %[pos], %[e], %[len]\n\t" \
         "s_cmp_lt_u32 %[pos], 64\n\t" \
-        "s_cbranch_scc0 3f\n" \
-        "1:\n\t"                                    /* (pos < 64 here) */ \
-        "s_lshl_b64 %[tmp], -1, %[pos]\n\t" \
-        "s_and_b64 %[tmp], %[tmp], %[E]\n\t" \
-        "s_ff1_i32_b64 %[e], %[tmp]\n\t"            /* first event at or after pos (-1: none) */ \
-        "s_cmp_lt_i32 %[e], 0\n\t" \
-        "s_cbranch_scc0 9b\n\t" \
-        "s_branch 30b\n" \
+        "s_cbranch_scc1 1b\n\t" \
+        "s_branch 3f\n" \
         "41:\n\t" \
         "s_mov_b32 %[e], %[e2]\n" \
         "4:\n\t" \
@@ -302,9 +301,11 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         "s_branch 5b\n" \
         "8:\n\t" \
         "s_add_u32 %[pos], %[e], 1\n\t"             /* a literal after all (encoder.cpp:367) */ \
-        "s_cmp_lt_u32 %[pos], 64\n\t" \
-        "s_cbranch_scc1 1b\n\t" \
-        "s_branch 3f\n" \
+        "s_lshl_b64 %[tmp], -2, %[e]\n\t"           /* events above e (none for e = 63: the shift leaves nothing) */ \
+        "s_and_b64 %[tmp], %[tmp], %[E]\n\t" \
+        "s_cbranch_scc0 30b\n\t" \
+        "s_ff1_i32_b64 %[e], %[tmp]\n\t" \
+        "s_branch 9b\n" \
         /* The nearest earlier lane with my hash was skipped and the hash has further members: the candidate is the most   */ \
         /* recent VISITED lane with my hash, else the table's (encoder.cpp:344-346: only probed positions are entered).    */ \
         /* Round 2 left the loop here for ~67 instructions of C++; on data with few distinct trigrams (4-symbol: 59 GB/s) */ \
@@ -350,17 +351,13 @@ __device__ __forceinline__ void l1_fast_walk(uint64_t E, uint32_t info, uint32_t
         : [E] "s"(E), [info] "v"(info), [nact] "s"(nact), [hash] "v"(X.hash), [wlo] "v"(X.wlo), [whi] "v"(X.whi), \
           [candbase] "s"(X.candbase), [hardok] "s"(X.hardok) \
         : "scc", "vcc"
-    if (FIRST)
+    if (FIRST)                                            // (pos = 0: the body starts with "the first event at or after pos")
         asm volatile(
-            "s_ff1_i32_b64 %[e], %[E]\n\t"              // the group's first event (-1: none)
-            "s_cmp_lt_i32 %[e], 0\n\t"
-            "s_cbranch_scc1 30f\n"
             ZZ_L1_WALK_BODY ZZ_L1_WALK_OPERANDS);
     else
         asm volatile(
             "s_cmp_gt_u32 %[pos], 63\n\t"
-            "s_cbranch_scc1 3f\n\t"
-            "s_branch 1f\n"
+            "s_cbranch_scc1 3f\n"
             ZZ_L1_WALK_BODY ZZ_L1_WALK_OPERANDS);
 #undef ZZ_L1_WALK_BODY
 #undef ZZ_L1_WALK_OPERANDS

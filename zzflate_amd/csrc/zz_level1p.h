@@ -52,9 +52,6 @@ namespace zz {
 #ifndef ZZ_L1P_PRIO_E
 #define ZZ_L1P_PRIO_E 0         // ... and of the emitter
 #endif
-#ifndef ZZ_L1P_R2
-#define ZZ_L1P_R2 1             // 1: the short form of R (sentinel slot for lanes that are not cross lanes, "none" = 64); 0: the round's first form
-#endif
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 #define ZZ_L1P_NONE 64u          // win[]: no lane of the block with that hash was visited
@@ -99,7 +96,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             l1_group_barrier();                                          // B_g
             const uint32_t cin = uniform(X->scal[0]);                    // (>= 64: the block in front was covered too)
             mycout = cin > ZZ_WAVE ? cin - ZZ_WAVE : 0u;
-            X->win[lane] = ZZ_L1P_R2 ? (uint8_t)ZZ_L1P_NONE : (uint8_t)0x80;
+            X->win[lane] = (uint8_t)ZZ_L1P_NONE;
             X->told[lane] = (g + 1) << 16;
             if (lane == 0) X->scal[0] = mycout;
             l1_group_barrier();                                          // B_g+1
@@ -142,22 +139,15 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint32_t talt = 0;
             uint64_t wa = 0, wa2 = 0;
             // (lanes that are not cross lanes point at the sentinel slot: what they read there says "the candidate as read")
-            const uint32_t qa = xd ? qx : (ZZ_L1P_R2 ? ZZ_L1P_SELF : 0u);
+            const uint32_t qa = xd ? qx : ZZ_L1P_SELF;
             if (XD) {
                 // what the table held under this hash BEFORE block g - 1: its owner publishes that, tagged with the block, as soon as
                 // it has settled its own cross lanes (right after B_g-1; this wavefront has repaired block g - 2 since)
                 uint32_t v;
-#if ZZ_L1P_R2
                 do {
                     ZZ_C(13, 1);
                     v = *(volatile lds_u32*)&X->told[qa];
                 } while (ballot((v >> 16) != g) & XD);                   // (the scalar AND of two masks: no select, no second compare)
-#else
-                do {
-                    ZZ_C(13, 1);
-                    v = *(volatile lds_u32*)&X->told[qa];
-                } while (ballot(xd && (v >> 16) != g));
-#endif
                 talt = xd ? (v & 0xFFFFu) : 0u;
                 if (xd) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(talt, 1u), wa, wa2);      // (a gather costs the address path per lane)
             }
@@ -166,7 +156,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             const uint64_t lostmask = ballot(active && rb != (uint32_t)(uint16_t)(p + 1));
             const uint32_t left = active ? n - p : 0;
             const uint32_t cap17 = INT ? 8u * (ZZ_WI_CAP + 1) : (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;
-            uint64_t myset = ZZ_L1P_R2 ? self_bit : 0;                   // the lanes of the block with my hash, myself included
+            uint64_t myset = self_bit;                  // the lanes of the block with my hash, myself included
             uint32_t infoB = 0;
             if (lostmask) {
                 uint32_t W = (uint32_t)lane;
@@ -195,7 +185,6 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint32_t cin;
             uint32_t told, info;
             uint64_t x;                                                  // the candidate's first eight bytes XOR mine
-#if ZZ_L1P_R2
             {
                 // Everything between the barrier and the walk is on the packet's critical path, instruction by instruction. Both
                 // reads go out at once and unconditionally: a lane that is not a cross lane reads the sentinel (win[65] = 65 = its
@@ -235,41 +224,6 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     info = sel_lanes(LDM, info3, info);
                 }
             }
-#else
-            {
-                const uint32_t sc = X->scal[0];
-                const uint32_t r = XD ? X->win[qa] : 0u;                 // the highest visited lane of block g - 1 with my hash (0x80: none)
-                // q itself (the highest lane of its set: the LDS leaves the highest lane's store in the slot): the table's entry as
-                // read; nobody: the entry from before the block; a lower lane: its bytes are not here
-                const bool use3 = xd && (r & 0x80u);
-                const bool ldm = xd && !use3 && r != qa;
-                const uint32_t toldh = base - ZZ_WAVE + r + 1u;
-                told = use3 ? talt : (ldm ? toldh : oldraw);
-                // the block behind is waiting for this (its cross lanes' second candidate): out first
-                X->told[lane] = told | ((g + 1) << 16);
-                __builtin_amdgcn_sched_barrier(0);                       // (nothing that waits for the candidates' bytes may move in front of that store)
-                cin = uniform(sc);
-                const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
-                x = w ^ c;
-                uint32_t la = equal_bits128(x, w2 ^ c2, cap17) >> 3;
-                if (!told) la = 0;
-                info = infoB | (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la);
-                if (XD && ballot(ldm)) {
-                    ZZ_C(14, 1);
-                    // a lower lane of block g - 1: its bytes come from the cache now (that block's owner has just read them) and the
-                    // walk waits for them here -- still cheaper than its out-of-line path, which such a lane took until it was measured
-                    // (2 per block of DNA-like data, 1.2 of XML)
-                    uint64_t l0 = 0, l1 = 0;
-                    if (ldm) l1p_ld128<!INT>(SRC, toldh - 1, l0, l1);
-                    const uint64_t x3 = w ^ l0;
-                    const uint32_t la3 = equal_bits128(x3, w2 ^ l1, cap17) >> 3;
-                    if (ldm) {
-                        x = x3;
-                        info = infoB | (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3);
-                    }
-                }
-            }
-#endif
             const uint64_t E = ballot((info & (ZZ_WI_HARD | 0x1Cu | (0x1Cu << ZZ_WI_LENB_SHIFT))) != 0);
             {
                 const uint32_t endl = (uint32_t)lane + (info & 31u);
@@ -352,15 +306,10 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             }
             {
                 // for the block behind: per lane the highest visited lane with its hash; the match end carried over
-#if ZZ_L1P_R2
                 // (v_ffbh gives -1 for 0 and the addition saturates: 63 - min is 64 = "none" by itself, no compare, no select)
                 const uint64_t sv = myset & committed;
                 const uint32_t fh = ffbh_or_ones((uint32_t)(sv >> 32)), fl = add_sat_k<32>(ffbh_or_ones((uint32_t)sv));
                 X->win[lane] = (uint8_t)(63u - (fh < fl ? fh : fl));
-#else
-                const uint64_t sv = (myset | (1ull << lane)) & committed;
-                X->win[lane] = (uint8_t)(sv ? 63u - (uint32_t)__builtin_clzll(sv) : 0x80u);
-#endif
                 mycout = pos > ZZ_WAVE ? pos - ZZ_WAVE : 0u;
                 if (lane == 0) X->scal[0] = mycout;
             }
