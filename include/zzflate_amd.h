@@ -131,6 +131,16 @@ int zz_encode_finish(zz_ctx* ctx, uint64_t* out_len);
  * would run out of room and silently leave a truncated stream, ZZ_E_NOSPACE is returned. */
 int zz_encode_stream_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                             int format, int level, void* hip_stream);
+/* The reference's OWN threaded == true split (zzflate.cpp:67-78 divideInRanges, :97-155 WriteDeflateStream) for device-resident
+ * data: `count` ranges of ceil(n / count) bytes -- std::thread::hardware_concurrency() of them in the reference, the caller's
+ * number here --, every range a fresh encoder whose non-final output ends with one stored byte, joined in order; n < 100 * count
+ * gives the single encoder's stream (:84). Bit-identical to what ZzFlateEncode(threaded = true) writes on a machine with `count`
+ * hardware threads at levels 0, 2, 3 (tests/golden/ranges.json holds such streams); level 1 returns ZZ_E_LEVEL: the reference's
+ * threaded level-1 stream does not inflate, use packet mode. One wavefront per range: a compatibility
+ * mode (packet mode -- zz_encode_device -- is the throughput mode and cuts <= 32 KiB ranges instead).
+ * Host entry points take this path when ZZFLATE_RANGES=<count> is set (threaded != 0, levels 0, 2, 3). n < 2 GiB. */
+int zz_encode_ranges_device(zz_ctx* ctx, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                            int format, int level, uint32_t count, void* hip_stream);
 /* The same stream in the form ZzFlateEncodeToCallback gives it (zzflate.cpp:197-222): the encoder writes into
  * library-owned chunks of 1,000,000 bytes and opens a new one when the current one is not "enough" for the next block
  * (outputbitstream.h:171-201), which at level 1 also decides the block lengths. d_dst receives header + stream +

@@ -182,6 +182,9 @@ double zzref_bench(int mode, const uint8_t* base, uint64_t nslices, uint64_t sli
 }
 
 // ---- checksums (adler.cpp:5-43, crc.cpp:24-33) ---------------------------------------------------
+// what the reference's threaded=true path divides the input by on THIS machine (zzflate.cpp:97): goldens made from
+// zzref_encode(threaded=1) record it (tests/golden/make_ranges.py)
+uint32_t zzref_hardware_concurrency() { return std::thread::hardware_concurrency(); }
 uint32_t zzref_adler32x(uint32_t start, const uint8_t* p, uint64_t n) { return adler32x(start, p, n); }
 uint32_t zzref_combine(uint32_t a, uint32_t b, uint64_t lenb) { return combine(a, b, lenb); }
 uint32_t zzref_crc32(const uint8_t* p, uint64_t n, uint32_t start) { return crc32(p, n, start); }

@@ -1072,6 +1072,37 @@ uint64_t zzo_encode_packets(uint8_t* dest, uint64_t cap, const uint8_t* src, uin
     return zzo_encode_packets_warm(dest, cap, src, n, format, level, packet_size, 0);
 }
 
+/* The reference's OWN threaded=true split (zzflate.cpp:67-78 divideInRanges, :81-156 WriteDeflateStream): `count` ranges of
+ * step = ceil(n / count) bytes -- count = std::thread::hardware_concurrency() there, a parameter here --, every range the
+ * packet recipe above (fresh encoder; non-final ranges end with the one stored byte), joined in order; an input shorter
+ * than 100 * count bytes goes through the single encoder (:84). A range's encoder sees destLen / count bytes of room (:98);
+ * with a roomy destination that changes nothing at levels 0, 2, 3. (Level 1's threaded stream is invalid in the reference,
+ * a fixed block's length follows from the room, and the non-final ranges' blocks are never closed.) */
+uint64_t zzo_encode_ranges(uint8_t* dest, uint64_t cap, const uint8_t* src, uint64_t n, int format, int level, uint32_t count)
+{
+    if (count == 0) return ZZO_ERROR;
+    if (n < 100ull * count) return zzo_encode(dest, cap, src, n, format, level);     /* :84 */
+    uint8_t h[10];
+    int hl = header_bytes(format, h);
+    if (level < 0 || level > 3 || cap < (uint64_t)hl) return ZZO_ERROR;
+    memcpy(dest, h, (size_t)hl);
+    uint64_t total = (uint64_t)hl;
+    const uint64_t step = (n + count - 1) / count;            /* :70 */
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint64_t off = step * k;                        /* :73 */
+        const uint64_t end = k + 1 == count ? n : step * (k + 1);   /* :75 */
+        uint64_t w = zzo_packet(level, src, off, end - off, k + 1 == count, dest + total, cap - total);   /* :101-125 */
+        if (w == ZZO_ERROR) return ZZO_ERROR;
+        total += w;                                           /* :134-155 */
+    }
+    bits_t t;
+    bs_init(&t, dest + total, cap - total, 1);
+    append_checksum(&t, format, src, n);
+    bs_flush(&t);
+    if (t.overflow) return ZZO_ERROR;
+    return total + t.pos;
+}
+
 /* outputbitstream.h:83-124 driven as zztest/TestBitOutput.cpp does */
 uint64_t zzo_bitstream(const uint64_t* bits, const int* counts, int n, uint8_t* out, uint64_t cap,
                        int* before_flush)

@@ -56,7 +56,16 @@ class Oracle:
         L.zzo_reverse.restype = u32; L.zzo_reverse.argtypes = [u32, ci]
         L.zzo_dist_bucket.restype = ci; L.zzo_dist_bucket.argtypes = [ci]
         L.zzo_bitstream.restype = u64
+        L.zzo_encode_ranges.restype = u64; L.zzo_encode_ranges.argtypes = [vp, u64, cp, u64, ci, ci, u32]
         self.L = L
+
+    def encode_ranges(self, d, fmt, lvl, count):
+        """the reference's own threaded=true split for a machine with `count` hardware threads (zzflate.cpp:67-78,97-155)"""
+        cap = 2 * len(d) + 4096
+        b = ctypes.create_string_buffer(cap)
+        n = self.L.zzo_encode_ranges(b, cap, d, len(d), fmt, lvl, count)
+        assert n != 0xFFFFFFFFFFFFFFFF
+        return b.raw[:n]
 
     def encode(self, d, fmt, lvl, cap=None):
         """zzo_encode into a destination of `cap` bytes (default: roomy). At level 1 the capacity decides the block

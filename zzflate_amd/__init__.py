@@ -76,6 +76,7 @@ def _load():
         "zz_encode_device_async": (i32, [vp, vp, u64, vp, u64, i32, i32, u32, vp]),
         "zz_encode_finish": (i32, [vp, pu64]),
         "zz_encode_stream_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, vp]),
+        "zz_encode_ranges_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, u32, vp]),
         "zz_encode_stream_chunks_device": (i32, [vp, vp, u64, vp, u64, pu64, i32, i32, pu64, u32, ctypes.POINTER(u32), vp]),
         "zz_encode_shard_device": (i32, [vp, vp, u64, u64, i32, vp, u64, pu64, ctypes.POINTER(u32), i32, i32, u32, vp]),
         "zz_encode_shard_device_async": (i32, [vp, vp, u64, u64, i32, vp, u64, i32, i32, u32, vp]),
@@ -278,6 +279,15 @@ class Context:
         st = self._stream() if stream is None else stream
         _check(lib.zz_encode_stream_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
                                            int(level), st))
+        return out.value
+
+    def encode_ranges(self, src, n, dst, cap, count, format=Format.Zlib, level=2, stream=None):
+        """The reference's own threaded=true split for a machine with ``count`` hardware threads (zzflate.cpp:67-78,97-155):
+        ``count`` ranges of ceil(n / count) bytes, one encoder (here: one wavefront) each. Levels 0, 2, 3."""
+        out = ctypes.c_uint64(0)
+        st = self._stream() if stream is None else stream
+        _check(lib.zz_encode_ranges_device(self._h, self._ptr(src), n, self._ptr(dst), cap, ctypes.byref(out), int(format),
+                                           int(level), int(count), st))
         return out.value
 
     def encode_stream_chunks(self, src, n, dst, cap, format=Format.Zlib, level=1, stream=None):

@@ -736,6 +736,100 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
     return ZZ_OK;
 }
 
+// The reference's OWN threaded=true split (zzflate.cpp:67-78 divideInRanges, :97-155): `count` ranges of ceil(n / count) bytes
+// -- count is std::thread::hardware_concurrency() there, the caller's choice here --, every range a fresh encoder, joined in
+// order. Packet mode replaces this split by fixed ranges of <= 32 KiB because a GPU wants thousands of ranges;
+// this entry point reproduces the reference's bytes for a given count: one WAVEFRONT per range (k_stream_l2: a range is one
+// dependency chain, and longer than the packet kernels' 16-bit positions allow), so it is a compatibility mode like the
+// sequential stream. Levels 0, 2, 3: at level 1 the reference's threaded stream is invalid (the block
+// lengths follow from the room, destLen / count per range, and the joined stream does not inflate), so there is nothing to equal.
+static int encode_ranges(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d_dst, uint64_t cap, int format, int level,
+                         uint32_t count, hipStream_t st, zz_result* host_res)
+{
+    if (count == 0 || count > 4096) { set_err("ranges: count must be 1..4096"); return ZZ_E_ARG; }
+    if (level == 1) { set_err("ranges: the reference's threaded level-1 stream is invalid (block lengths follow from destLen / count); use packet mode"); return ZZ_E_LEVEL; }
+    if (n < 100ull * count)                                               // zzflate.cpp:84: the single encoder
+        return encode_stream(c, d_src, n, d_dst, cap, format, level, false, nullptr, st, host_res);
+    if (c->pend.active) { set_err("a call enqueued with zz_encode_device_async has not been finished on this context"); return ZZ_E_ARG; }
+    if (level < 0 || level > 3) { set_err("level must be 0..3 (zzflate.cpp:201,230)"); return ZZ_E_LEVEL; }
+    if (!d_dst || !d_src) { set_err("null buffer"); return ZZ_E_ARG; }
+    if (n >= (1ull << 31)) { set_err("ranges: input must be < 2 GiB (the reference funnels lengths through int)"); return ZZ_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const int hl = header_len(format), tl = trailer_len(format);
+    if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
+    const int cks_kind = cks_kind_for(format);
+    const uint64_t step = (n + count - 1) / count;                        // zzflate.cpp:70
+    c->have_time = false;
+    c->have_last = false;
+    HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(zz_result), st));
+    HIPCHK(hipMemsetAsync(c->d_cks_total, 0, sizeof(zz_cks_total), st));
+    HIPCHK(hipMemsetAsync(c->d_err, 0, 4 * sizeof(uint32_t), st));
+    const uint32_t P = 32768, npk_c = (uint32_t)((n + P - 1) / P);         // checksum chunks
+    int rc = ensure_workspace(c, 0, npk_c > count ? npk_c : count, 0);
+    if (rc) return rc;
+    zz_packet_params pp;
+    memset(&pp, 0, sizeof pp);
+    pp.src = d_src; pp.n = n; pp.halo = 0; pp.last_is_final = 1; pp.err = c->d_err; pp.prof = c->d_prof; pp.tail = c->d_tail;
+    pp.packet_size = P; pp.npk = npk_c; pp.cks_kind = cks_kind; pp.cks = c->cks; pp.sizes = c->sizes;
+    if (cks_kind == ZZ_CKS_CRC) hipLaunchKernelGGL(k_crc32_packets, dim3(npk_c < 2048 ? npk_c : 2048), dim3(ZZ_CRC_THREADS), 0, st, pp);
+    else if (cks_kind == ZZ_CKS_ADLER) hipLaunchKernelGGL(k_adler_packets, dim3(npk_c < 4096 ? npk_c : 4096), dim3(ZZ_WAVE), 0, st, pp);
+    if (level == 0) {
+        const uint64_t total = (uint64_t)(count - 1) * l0_range_bytes(step, false) + l0_range_bytes(n - (uint64_t)(count - 1) * step, true);
+        if ((uint64_t)hl + total + tl > cap) { set_err("destination too small"); return ZZ_E_NOSPACE; }
+        hipLaunchKernelGGL(k_ranges_l0, dim3(count), dim3(256), 0, st, d_src, n, step, d_dst + hl);
+        hipLaunchKernelGGL(k_put_small, dim3(1), dim3(1), 0, st, (uint8_t*)nullptr, 0ull, 0u, c->d_res, total);
+    } else {
+        // per range: every block may fall back to stored blocks of <= 65535 bytes, plus the closing stored byte
+        const uint64_t bound = (step + (step / 65535 + 2) * 5 + (step / 400000 + 2) * 8 + 64 + 15) & ~15ull;
+        if (bound > 0xFFFFFFF0ull) { set_err("ranges: range too large"); return ZZ_E_ARG; }
+        if (bound * count > c->slots_cap) {
+            (void)hipFree(c->slots); c->slots = nullptr; c->slots_cap = 0;
+            HIPCHK(hipMalloc(&c->slots, bound * count));
+            c->slots_cap = bound * count;
+        }
+        if ((uint64_t)ZZ_ST_SCRATCH_BYTES * count > c->l2_scratch_cap) {
+            (void)hipFree(c->l2_scratch); c->l2_scratch = nullptr; c->l2_scratch_cap = 0;
+            HIPCHK(hipMalloc(&c->l2_scratch, (uint64_t)ZZ_ST_SCRATCH_BYTES * count));
+            c->l2_scratch_cap = (uint64_t)ZZ_ST_SCRATCH_BYTES * count;
+        }
+        zz_st_params q;
+        memset(&q, 0, sizeof q);
+        q.pk = pp; q.pk.npk = count; q.pk.slots = c->slots; q.pk.slot_stride = (uint32_t)bound; q.pk.cks_kind = ZZ_CKS_NONE;
+        q.scratch = c->l2_scratch; q.range_step = step;
+        q.ctl.cap = ~0ull;
+        if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));
+        hipLaunchKernelGGL(k_stream_l2, dim3(count), dim3(ZZ_WAVE), 0, st, q);
+        if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
+        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(ZZ_SCAN_THREADS), 0, st, c->sizes, count, c->offsets, c->d_res);
+        hipLaunchKernelGGL(k_compact, dim3(count), dim3(256), 0, st, c->slots, (uint32_t)bound, c->sizes, c->offsets, count,
+                           d_dst + hl, cap >= (uint64_t)(hl + tl) ? cap - hl - tl : 0, c->d_res);
+    }
+    if (cks_kind != ZZ_CKS_NONE)
+        hipLaunchKernelGGL(k_cks_reduce, dim3(1), dim3(ZZ_RED_THREADS), 0, st, c->cks, npk_c, P, n, cks_kind, c->d_cks_total);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1), 0, st, d_dst, cap, format, c->d_cks_total, n, c->d_res);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, sizeof(zz_result), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_err, c->d_err, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *host_res = *c->h_res;
+    if (c->h_err[0]) { set_err("internal: output slot overflow"); return ZZ_E_NOSPACE; }
+    if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
+    return ZZ_OK;
+}
+
+extern "C" int zz_encode_ranges_device(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
+                                       int format, int level, uint32_t count, void* hip_stream)
+{
+    if (out_len) *out_len = ~0ull;
+    if (!c || !out_len) { set_err("null argument"); return ZZ_E_ARG; }
+    if (format < 0 || format > 2) format = ZZ_DEFLATE;
+    zz_result r;
+    int rc = encode_ranges(c, (const uint8_t*)d_src, n, (uint8_t*)d_dst, cap, format, level, count, (hipStream_t)hip_stream, &r);
+    if (rc) return rc;
+    *out_len = r.total_bytes;
+    return ZZ_OK;
+}
+
 extern "C" int zz_encode_stream_device(zz_ctx* c, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_len,
                                        int format, int level, void* hip_stream)
 {
@@ -1437,6 +1531,28 @@ static int encode_host_sequential(zz_ctx* c, const uint8_t* src, uint64_t n, int
     return ZZ_OK;
 }
 
+// ZZFLATE_RANGES=<count>, threaded != 0, levels 0, 2, 3: the reference's own split (encode_ranges) instead of packets
+static int encode_host_ranges(zz_ctx* c, const uint8_t* src, uint64_t n, int format, int level, uint32_t count, host_sink& sink)
+{
+    const uint64_t hl = header_len(format), tl = trailer_len(format);
+    const uint64_t bound = n + (n / 65535 + 2 * (uint64_t)count + 2) * 5 + (n / 400000 + 2 * (uint64_t)count + 2) * 8 + 6ull * count + 64 + hl + tl;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_stage(c, n, bound);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpy(c->stage_in, src, n, hipMemcpyHostToDevice));
+    zz_result r;
+    rc = encode_ranges(c, c->stage_in, n, c->stage_out, bound, format, level, count, nullptr, &r);
+    if (rc) return rc;
+    const uint64_t total = r.total_bytes;
+    std::vector<uint8_t> host(total);
+    if (total) HIPCHK(hipMemcpy(host.data(), c->stage_out, total, hipMemcpyDeviceToHost));
+    sink.raw(host.data(), hl);
+    sink.put(host.data() + hl, total - hl - tl);
+    sink.raw(host.data() + total - tl, tl);
+    sink.flush();
+    return ZZ_OK;
+}
+
 static int encode_host(const uint8_t* src, uint64_t n, const zz_config* cfg, host_sink& sink)
 {
     const int level = cfg->level;
@@ -1455,6 +1571,15 @@ static int encode_host(const uint8_t* src, uint64_t n, const zz_config* cfg, hos
         rc = lease.take(devs[0]);
         if (rc) return rc;
         return encode_host_sequential(lease.v[0], src, n, format, level, sink);
+    }
+    {
+        const char* e = getenv("ZZFLATE_RANGES");                         // (read per call: tests switch it)
+        const int count = e ? atoi(e) : 0;
+        if (count > 0 && n > 0 && level != 1 && level <= 3) {
+            rc = lease.take(devs[0]);
+            if (rc) return rc;
+            return encode_host_ranges(lease.v[0], src, n, format, level, (uint32_t)count, sink);
+        }
     }
     const uint64_t slab = slab_bytes(P);
     const uint64_t nslab = (n + slab - 1) / slab;

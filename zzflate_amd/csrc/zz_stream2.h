@@ -223,8 +223,15 @@ __device__ __forceinline__ void st_stored_block(bitring& ring, const uint8_t* p,
 
 struct zz_st_params {
     zz_packet_params pk;      // src, n, slots (one big output slot), sizes[0], err
-    uint8_t* scratch;         // ZZ_ST_SCRATCH_BYTES
+    uint8_t* scratch;         // ZZ_ST_SCRATCH_BYTES (per range)
     zz_stream_ctl ctl;        // callback form: log of the EnsureOutputLength calls (the host cuts the chunks from it)
+    // The reference's own threaded=true split (zzflate.cpp:67-78,97-125): range_step != 0 and one workgroup per range. Range r is
+    // src[r * range_step, min((r + 1) * range_step, n)), encoded by a fresh encoder (cold table) into slot r; a range that is
+    // not the last compresses all but its last byte with BFINAL clear and closes with that byte as a stored block
+    // (SetLevel(0); AddData(e - 1, e)): byte-aligned, so the ranges' outputs concatenate. Positions stay relative to the
+    // whole input: a candidate's room for backward extension counts the bytes in front of the range too, as the reference's
+    // pointer arithmetic does (SURVEY.md App. B D4 -- the packet kernels' `before`).
+    uint64_t range_step;
 };
 
 __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
@@ -254,14 +261,21 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
     const int lane = lane_id();
     st_state S;
     S.T = T; S.base = P.src; S.end = P.src + P.n;
-    S.tokens = (st_token*)Q.scratch;
-    S.cov = (unsigned long long*)(Q.scratch + ZZ_ST_MAX_RECORDS * 8);
+    // (one workgroup per range; the sequential stream is the one-range case)
+    const uint32_t rg = blockIdx.x;
+    const uint64_t rstart = Q.range_step ? (uint64_t)rg * Q.range_step : 0;
+    const bool rlast = !Q.range_step || rg + 1 == gridDim.x;
+    const uint64_t rend = rlast ? P.n : rstart + Q.range_step;
+    const uint64_t cend = rlast ? rend : rend - 1;                       // what the compressing AddData sees (zzflate.cpp:116)
+    uint8_t* const scratch = Q.scratch + (uint64_t)rg * ZZ_ST_SCRATCH_BYTES;
+    S.tokens = (st_token*)scratch;
+    S.cov = (unsigned long long*)(scratch + ZZ_ST_MAX_RECORDS * 8);
     S.mst = S.cov + ZZ_ST_WORDS;
     uint32_t* mcount = (uint32_t*)(S.mst + ZZ_ST_WORDS);
 
     for (int i = lane; i < ZZ_HASH_SIZE; i += ZZ_WAVE) T[i] = 0;       // cold table (encoder.cpp:533-536)
     bitring ring;
-    ring_init(ring, ring_words, P.slots);
+    ring_init(ring, ring_words, P.slots + (uint64_t)rg * P.slot_stride);
     uint32_t* const out0 = ring.out32;
 
     // "bytes stored" as EnsureOutputLength sees them (outputbitstream.h:167-176): exact at the last Flush (the end of a
@@ -272,10 +286,10 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
         const uint64_t bits = (uint64_t)(ring.out32 - out0) * 32 + ring.bitpos;
         return (flush_bits >> 3) + (((bits - flush_bits) >> 6) << 3);
     };
-    uint64_t pos = 0;                                                    // AddData loop (encoder.cpp:539-552)
-    while (pos < P.n) {
-        const uint64_t remaining = P.n - pos;
-        bool final = true;
+    uint64_t pos = rstart;                                               // AddData loop (encoder.cpp:539-552)
+    while (pos < cend) {
+        const uint64_t remaining = cend - pos;
+        bool final = rlast;
         uint32_t byteCount = (uint32_t)remaining;
         if (remaining > ZZ_ST_MAX_BLOCK) { byteCount = ZZ_ST_MAX_BLOCK; final = false; }   // :518-522
         S.bs = pos;
@@ -426,12 +440,39 @@ __global__ __launch_bounds__(ZZ_WAVE) void k_stream_l2(zz_st_params Q)
         pos += length;
         __syncthreads();
     }
+    if (!rlast) st_stored_block(ring, P.src + rend - 1, 1, false);      // zzflate.cpp:118-120
     const uint64_t bytes = (uint64_t)(ring.out32 - out0) * 4 + ring_finish(ring);
     if (lane == 0) {
-        P.sizes[0] = (uint32_t)bytes;
+        P.sizes[rg] = (uint32_t)bytes;
         if (bytes > (uint64_t)P.slot_stride) atomicOr(P.err, 1u);
         if (Q.ctl.log_n) *Q.ctl.log_n = nlog;
     }
+}
+
+// Level 0 over the same ranges: stored blocks of at most 65535 bytes (encoder.cpp:482-502) straight to their final place --
+// every size is known beforehand. One workgroup per range.
+__host__ __device__ __forceinline__ uint64_t l0_chain_bytes(uint64_t len) { return len + 5 * ((len + 0xFFFE) / 0xFFFF); }
+__host__ __device__ __forceinline__ uint64_t l0_range_bytes(uint64_t len, bool last) { return last ? l0_chain_bytes(len) : l0_chain_bytes(len - 1) + 6; }
+__global__ __launch_bounds__(256) void k_ranges_l0(const uint8_t* src, uint64_t n, uint64_t step, uint8_t* dst)
+{
+    const uint32_t rg = blockIdx.x, nr = gridDim.x;
+    uint64_t o = 0;
+    for (uint32_t r = 0; r < rg; ++r) o += l0_range_bytes(step, false);
+    const uint64_t rstart = (uint64_t)rg * step;
+    const bool last = rg + 1 == nr;
+    const uint64_t rend = last ? n : rstart + step;
+    const uint64_t cend = last ? rend : rend - 1;
+    uint8_t* out = dst + o;
+    for (uint64_t p = rstart; p < cend; p += 0xFFFF) {
+        const uint32_t c = (uint32_t)(cend - p < 0xFFFF ? cend - p : 0xFFFF);
+        if (threadIdx.x == 0) {
+            out[0] = (last && p + c == cend) ? 1 : 0;
+            out[1] = (uint8_t)c; out[2] = (uint8_t)(c >> 8); out[3] = (uint8_t)~c; out[4] = (uint8_t)(~c >> 8);
+        }
+        coop_copy(out + 5, src + p, c, threadIdx.x, blockDim.x);
+        out += 5 + c;
+    }
+    if (!last && threadIdx.x == 0) { out[0] = 0; out[1] = 1; out[2] = 0; out[3] = 0xFE; out[4] = 0xFF; out[5] = src[rend - 1]; }
 }
 
 }  // namespace zz
