@@ -835,7 +835,12 @@ static int64_t block_extended(enc_t* e, const uint8_t* src, int64_t n, int final
     e->ntok = 0;
     for (int64_t p = 0; p < target;) {                       /* greedy parse with one-step lazy evaluation */
         int len = L[p];
+        /* ZZO_LAZY_EVERYWHERE (a measurement build only, tools/lazy_artefact.py: what the exception for lane 63 costs in ratio) */
+#ifdef ZZO_LAZY_EVERYWHERE
+        const int defer = len && len < X_CAP && L[p + 1] > len;
+#else
         const int defer = len && len < X_CAP && (p & 63) != 63 && L[p + 1] > len;   /* (L[target] = 0) */
+#endif
         if (!len || defer) { p++; continue; }
         if (len == X_CAP) len = match_forward(e, src + p, src + p - Dd[p], n - p < MAX_LEN ? (int)(n - p) : MAX_LEN);
         push_token(e, p, Dd[p], len);
