@@ -65,6 +65,15 @@ def test_other_counts_containers_and_edges_equal_the_oracle(oracle):
         assert run(ctx, d, 0, lvl, 8) == oracle.encode(d, 0, lvl)
 
 
+def test_long_ranges_many_blocks_each(oracle):
+    # 24 MiB in 5 ranges of 4.8 MiB: ten dynamic blocks per range (500,000 bytes / 20,000 records each), the table carried across
+    # them, ranges 1..4 with the bytes of the range in front as room for backward extension
+    d = synth("words", 12 << 20, 21) + synth("runs", 4 << 20, 22) + synth("words", 8 << 20, 23)
+    ctx = zz.Context(0)
+    for lvl in (2, 3):
+        assert run(ctx, d, 1, lvl, 5) == oracle.encode_ranges(d, 1, lvl, 5), lvl
+
+
 def test_level1_is_refused_with_the_reason():
     ctx = zz.Context(0)
     d = synth("words", 50000, 1)

@@ -54,6 +54,23 @@ for it in range(cases):
             if mode == 2 and rng.random() < 0.4: rng.choice([4, 5, 6])
         continue
     src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    if os.environ.get("ZZ_FUZZ_RANGES") == "1" and len(d) > 0:
+        # every case through the reference's own threaded split (zz_encode_ranges_device) with a count of its own (a separate
+        # run: ZZ_FUZZ_RANGES=1 python tools/fuzz_gpu.py ...), levels 0, 2, 3
+        count = 1 + (it * 13 + len(d)) % 40
+        rl = (0, 2, 3)[it % 3]
+        want = o.encode_ranges(d, fmt, rl, count)
+        cap = 2 * len(d) + 4096 + 16 * count
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        w = ctx.encode_ranges(src, len(d), dst, cap, count, fmt, rl)
+        got = dst[:w].cpu().numpy().tobytes()
+        if got != want or zlib.decompressobj(WB[fmt]).decompress(got) != d:
+            bad += 1
+            print("MISMATCH ranges", it, kind, len(d), count, rl, fmt, flush=True)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{it}.in"), "wb").write(d)
+        if (it + 1) % 100 == 0: print(f"{it + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+        continue
     if mode == 3 and len(d) > 0:
         # the reference's single-Encoder stream (threaded = false) into a tight or roomy destination, or in chunks
         if rng.random() < 0.5:
