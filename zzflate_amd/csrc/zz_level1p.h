@@ -168,10 +168,17 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 const int qa = (int)(ql << 2);
                 const uint64_t wq = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w);
                 const uint64_t wq2 = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(w2 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)w2);
-                const uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
                 const bool hard = (uint32_t)__builtin_popcountll(below) > 1u;
-                const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | (hard ? ZZ_WI_HARD : 0u)
-                                    | (lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT));
+                uint32_t lbf;                                            // the LENB field with its "16 or more" flag
+                if (INT) {
+                    // (interior blocks: "all sixteen bytes equal" is the only way to the cap, so the cap itself can BE the field's
+                    // value for that case -- length 16 and the flag -- and no compare-and-select follows the count)
+                    lbf = (equal_bits128(w ^ wq, w2 ^ wq2, (((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) >> ZZ_WI_LENB_SHIFT) << 3) >> 3) << ZZ_WI_LENB_SHIFT;
+                } else {
+                    const uint32_t lb = equal_bits128(w ^ wq, w2 ^ wq2, cap17) >> 3;
+                    lbf = lb > ZZ_WI_CAP ? ((ZZ_WI_CAP << ZZ_WI_LENB_SHIFT) | ZZ_WI_EXTB) : (lb << ZZ_WI_LENB_SHIFT);
+                }
+                const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | (hard ? ZZ_WI_HARD : 0u) | lbf;
                 infoB = dup ? di : 0u;
             }
             ZZ_T(0);
@@ -213,13 +220,15 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 cin = uniform(sc);
                 const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
                 x = w ^ c;
-                uint32_t la = equal_bits128(x, w2 ^ c2, cap17) >> 3;
+                // (interior blocks: the cap IS "16 | the flag", see LENB above: three instructions less between the barrier and the walk)
+                constexpr uint32_t CAPA = (ZZ_WI_CAP | ZZ_WI_EXTA) << 3;
+                uint32_t la = equal_bits128(x, w2 ^ c2, INT ? CAPA : cap17) >> 3;
                 if (!told) la = 0;
-                info = infoB | (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la);
+                info = infoB | (INT ? la : (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la));
                 if (LDM) {
                     const uint64_t x3 = w ^ l0;
-                    const uint32_t la3 = equal_bits128(x3, w2 ^ l1, cap17) >> 3;
-                    const uint32_t info3 = infoB | (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3);
+                    const uint32_t la3 = equal_bits128(x3, w2 ^ l1, INT ? CAPA : cap17) >> 3;
+                    const uint32_t info3 = infoB | (INT ? la3 : (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3));
                     x = ((uint64_t)sel_lanes(LDM, (uint32_t)(x3 >> 32), (uint32_t)(x >> 32)) << 32) | sel_lanes(LDM, (uint32_t)x3, (uint32_t)x);
                     info = sel_lanes(LDM, info3, info);
                 }
