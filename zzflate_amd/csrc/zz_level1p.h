@@ -59,8 +59,9 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct l1p_xch {
     uint32_t told[ZZ_WAVE + 4];    // per lane of block t - 1, t = the word's high half: the table's entry under the lane's hash BEFORE that block
     uint8_t win[ZZ_WAVE + 4];      // per lane of the block walked last: the highest VISITED lane of the block with the lane's hash, 64 = none; [65] = 65
-    uint32_t scal[4];              // [0]: the positions by which the block walked last runs into the next one
-};   // 356 bytes
+    uint16_t scal[ZZ_WAVE];        // [0]: the positions by which the block walked last runs into the next one. Every lane stores
+                                   // (lane l to [l]: no lane mask to set up for "lane 0 only"), only [0] is read
+};   // 468 bytes
 
 
 
@@ -83,6 +84,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
     for (uint32_t g = pw; g < NB; g += 2) {
+        const uint32_t tag = (g + 1) << 16;                               // told[]'s tag: "these are block g's"
         if (mycout >= 2 * ZZ_WAVE) {
             // A match found two blocks ago covers this block entirely (and the one between, which the other wavefront had probed by
             // then): nothing is probed, entered or walked -- the barriers, the carried match end and an empty token slot are all there
@@ -94,11 +96,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 l1p_ld128<true>(SRC, pn < n ? pn : n - 1, wn, wn2);
             }
             l1_group_barrier();                                          // B_g
-            const uint32_t cin = uniform(X->scal[0]);                    // (>= 64: the block in front was covered too)
+            const uint32_t cin = uniform((uint32_t)X->scal[0]);          // (>= 64: the block in front was covered too)
             mycout = cin > ZZ_WAVE ? cin - ZZ_WAVE : 0u;
             X->win[lane] = (uint8_t)ZZ_L1P_NONE;
-            X->told[lane] = (g + 1) << 16;
-            if (lane == 0) X->scal[0] = mycout;
+            X->told[lane] = tag;
+            X->scal[lane] = (uint16_t)mycout;
             l1_group_barrier();                                          // B_g+1
             *slot = 0;
             w = wn;
@@ -206,32 +208,36 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 const uint32_t t1 = use3 ? talt : toldh;
                 told = moved ? t1 : oldraw;
                 // the block behind is waiting for this (its cross lanes' second candidate): out first
-                X->told[lane] = told | ((g + 1) << 16);
+                X->told[lane] = told | tag;
                 const uint64_t LDM = ballot(moved) & ~ballot(use3);
-                uint64_t l0 = 0, l1 = 0;
-                if (LDM) {
-                    ZZ_C(14, 1);
-                    // a lower lane of block g - 1: its bytes come from the cache (that block's owner has just read them); asked for
-                    // before anything else so that the comparison below runs under the load (every lane loads: no lane mask to set
-                    // up; the others read their own candidate's line again) -- 0.2 times per block of text, 0.35 of the mix
-                    l1p_ld128u<!INT>(SRC, __builtin_elementwise_sub_sat(told, 1u), l0, l1);
-                }
-                __builtin_amdgcn_sched_barrier(0);                       // (nothing that waits for the candidates' bytes may move in front of that)
-                cin = uniform(sc);
-                const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
-                x = w ^ c;
                 // (interior blocks: the cap IS "16 | the flag", see LENB above: three instructions less between the barrier and the walk)
                 constexpr uint32_t CAPA = (ZZ_WI_CAP | ZZ_WI_EXTA) << 3;
-                uint32_t la = equal_bits128(x, w2 ^ c2, INT ? CAPA : cap17) >> 3;
-                if (!told) la = 0;
-                info = infoB | (INT ? la : (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la));
-                if (LDM) {
+                auto compare = [&]() {
+                    __builtin_amdgcn_sched_barrier(0);                   // (nothing that waits for the candidates' bytes may move in front of this)
+                    const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
+                    x = w ^ c;
+                    uint32_t la = equal_bits128(x, w2 ^ c2, INT ? CAPA : cap17) >> 3;
+                    if (!told) la = 0;
+                    info = infoB | (INT ? la : (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la));
+                };
+                // (ONE test of LDM, with the comparison in both arms: the test is scalar code on the critical path)
+                if (__builtin_expect(LDM == 0, 1)) {
+                    compare();
+                } else {
+                    ZZ_C(14, 1);
+                    // a lower lane of block g - 1: its bytes come from the cache (that block's owner has just read them); asked for
+                    // before anything else so that the comparison runs under the load (every lane loads: no lane mask to set
+                    // up; the others read their own candidate's line again) -- 0.2 times per block of text, 0.35 of the mix
+                    uint64_t l0, l1;
+                    l1p_ld128u<!INT>(SRC, __builtin_elementwise_sub_sat(told, 1u), l0, l1);
+                    compare();
                     const uint64_t x3 = w ^ l0;
                     const uint32_t la3 = equal_bits128(x3, w2 ^ l1, INT ? CAPA : cap17) >> 3;
                     const uint32_t info3 = infoB | (INT ? la3 : (la3 > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la3));
                     x = ((uint64_t)sel_lanes(LDM, (uint32_t)(x3 >> 32), (uint32_t)(x >> 32)) << 32) | sel_lanes(LDM, (uint32_t)x3, (uint32_t)x);
                     info = sel_lanes(LDM, info3, info);
                 }
+                cin = uniform(sc);
             }
             const uint64_t E = ballot((info & (ZZ_WI_HARD | 0x1Cu | (0x1Cu << ZZ_WI_LENB_SHIFT))) != 0);
             {
@@ -244,10 +250,13 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             ZZ_T(2); ZZ_C(12, (uint32_t)__builtin_popcountll(E)); ZZ_C(15, cin < 64 ? cin : 64);
             // ---- W: the walk (encoder.cpp:341-368 replayed over the event mask), starting behind the match carried in
             uint64_t mst = 0, usedB = 0;
-            uint64_t cov = cin >= ZZ_WAVE ? ~0ull : ((1ull << cin) - 1);
+            uint64_t cov;                                                // the lanes the match carried in covers: cin ones (all of them from 64 on)
+            asm("s_bfm_b64 %0, %1, 0\n\ts_cmp_lt_u32 %1, 64\n\ts_cselect_b64 %0, %0, -1" : "=&s"(cov) : "s"(cin) : "scc");
             l1_walk_x Xw;
             Xw.hash = h; Xw.wlo = (uint32_t)w; Xw.whi = (uint32_t)(w >> 32); Xw.candbase = base + 1; Xw.hardok = INT ? 1u : 0u;
-            Xw.ovlen = 0; Xw.ovcand1 = 0; Xw.ovmL = 0; Xw.ovmC = 0;
+            // (the overrides' lanes are named by ovmL / ovmC; what the other lanes hold is never looked at: no zeroing)
+            asm volatile("" : "=v"(Xw.ovlen), "=v"(Xw.ovcand1));
+            Xw.ovmL = 0; Xw.ovmC = 0;
             uint32_t& ovlen = Xw.ovlen; uint32_t& ovcand1 = Xw.ovcand1;
             uint64_t& ovmL = Xw.ovmL; uint64_t& ovmC = Xw.ovmC;
             uint32_t pos = cin;
@@ -320,7 +329,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 const uint32_t fh = ffbh_or_ones((uint32_t)(sv >> 32)), fl = add_sat_k<32>(ffbh_or_ones((uint32_t)sv));
                 X->win[lane] = (uint8_t)(63u - (fh < fl ? fh : fl));
                 mycout = pos > ZZ_WAVE ? pos - ZZ_WAVE : 0u;
-                if (lane == 0) X->scal[0] = mycout;
+                X->scal[lane] = (uint16_t)mycout;
             }
             ZZ_T(4);
             l1_group_barrier();                                          // B_g+1: block g has been walked
@@ -374,7 +383,7 @@ __device__ __forceinline__ void l1p_packet_parser(const zz_packet_params& P, uin
     // cold table (encoder.cpp:533-536): each parser clears its half
     uint4* t4 = (uint4*)T + pw * (ZZ_HASH_SIZE * sizeof(uint16_t) / 32);
     for (int i = lane; i < (int)(ZZ_HASH_SIZE * sizeof(uint16_t) / 32); i += ZZ_WAVE) t4[i] = make_uint4(0, 0, 0, 0);
-    if (pw == 0 && lane < 4) X->scal[lane] = 0;                          // block 0: nothing carried in
+    if (pw == 0) X->scal[lane] = 0;                                      // block 0: nothing carried in
     if (pw == 0) X->told[lane] = 0;                                      // (tag 0: no block's)
     if (pw == 1 && lane == 0) X->win[ZZ_L1P_SELF] = (uint8_t)ZZ_L1P_SELF; // the sentinel (zz_level1p.h, R)
     l1_group_barrier();                                                  // B_z
