@@ -251,7 +251,6 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             // ---- W: the walk (encoder.cpp:341-368 replayed over the event mask), starting behind the match carried in
             uint64_t mst = 0, usedB = 0;
             uint64_t cov;                                                // the lanes the match carried in covers: cin ones (all of them from 64 on)
-            asm("s_bfm_b64 %0, %1, 0\n\ts_cmp_lt_u32 %1, 64\n\ts_cselect_b64 %0, %0, -1" : "=&s"(cov) : "s"(cin) : "scc");
             l1_walk_x Xw;
             Xw.hash = h; Xw.wlo = (uint32_t)w; Xw.whi = (uint32_t)(w >> 32); Xw.candbase = base + 1; Xw.hardok = INT ? 1u : 0u;
             // (the overrides' lanes are named by ovmL / ovmC; what the other lanes hold is never looked at: no zeroing)
@@ -260,7 +259,13 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint32_t& ovlen = Xw.ovlen; uint32_t& ovcand1 = Xw.ovcand1;
             uint64_t& ovmL = Xw.ovmL; uint64_t& ovmC = Xw.ovmC;
             uint32_t pos = cin;
-            l1_fast_walk<false>(E, info, nact, pos, mst, cov, usedB, Xw);
+            // (ONE test of "the carried match covers the whole block" for both the cover mask and the walk's entry)
+            if (cin < ZZ_WAVE) {
+                asm("s_bfm_b64 %0, %1, 0" : "=s"(cov) : "s"(cin));
+                l1_fast_walk<true>(E, info, nact, pos, mst, cov, usedB, Xw);     // (<true>: pos < 64 is known, no test of its own)
+            } else {
+                cov = ~0ull;
+            }
             while (pos < nact) {
                 const int e = (int)pos;
                 ZZ_C(11, 1);
@@ -317,7 +322,10 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             ZZ_T(3);
             // visited lanes: every lane in front of `pos` that no match covers, plus the match starts
             uint64_t committed;
-            {
+            if (INT) {
+                // (an interior block's walk ends at or behind lane 63: "in front of pos" is every lane -- one instruction, not five)
+                asm("s_orn2_b64 %0, %2, %1" : "=s"(committed) : "s"(cov), "s"(mst) : "scc");
+            } else {
                 uint32_t t;
                 asm("s_min_u32 %1, %2, 64\n\ts_sub_u32 %1, 64, %1\n\ts_lshr_b64 %0, -1, %1\n\ts_andn2_b64 %0, %0, %3\n\ts_or_b64 %0, %0, %4"
                     : "=&s"(committed), "=&s"(t) : "s"(pos), "s"(cov), "s"(mst) : "scc");
