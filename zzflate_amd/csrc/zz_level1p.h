@@ -83,8 +83,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     ZZ_PROF_DECL
     uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
+    uint32_t xlo_next = pw ? 1u : 0xFFFF0000u;                            // block 1: base - 63 = 1; block 0: nothing can be a cross lane
     for (uint32_t g = pw; g < NB; g += 2) {
         const uint32_t tag = (g + 1) << 16;                               // told[]'s tag: "these are block g's"
+        const uint32_t xlo = xlo_next;
+        xlo_next = (g << 6) + (2 * ZZ_WAVE - (ZZ_WAVE - 1));              // block g + 2's: its base - 63
         if (mycout >= 2 * ZZ_WAVE) {
             // A match found two blocks ago covers this block entirely (and the one between, which the other wavefront had probed by
             // then): nothing is probed, entered or walked -- the barriers, the carried match end and an empty token slot are all there
@@ -122,15 +125,16 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             T[h] = (uint16_t)(p + 1);
             uint64_t wc, wc2;
             l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(oldraw, 1u), wc, wc2);     // (no candidate: the packet's first bytes, unused)
-            uint64_t wn = 0, wn2 = 0;                                    // this lane's bytes two blocks on: blocks are fixed, so the address is known
-            if (g + 2 < NB) {
+            uint64_t wn, wn2;                                            // this lane's bytes two blocks on: blocks are fixed, so the address is known
+            if (!INT) { wn = 0; wn2 = 0; }
+            if (INT || g + 2 < NB) {                                     // (an interior block has two whole blocks behind it: no test)
                 const uint32_t pn = p + 2 * ZZ_WAVE;
                 l1p_ld128u<!INT>(SRC, INT ? pn : (pn < n ? pn : n - 1), wn, wn2);
             }
             ZZ_WAVE_SYNC();
             const uint32_t rb = T[h];                                    // the slot holds whichever lane wrote last
             // cross lanes: the entry read is a position of block g - 1, entered speculatively while that block is being walked
-            const uint32_t xlo = g ? base - (ZZ_WAVE - 1) : 0xFFFF0000u;
+            // (xlo: base - 63, and for the packet's first block a value no entry can reach -- carried, one addition per block)
             const uint32_t qx = oldraw - xlo;                            // its lane there
             const bool xd = active && qx < ZZ_WAVE;
 #ifdef ZZ_L1P_X_NOCROSS
@@ -138,8 +142,10 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
 #else
             const uint64_t XD = ballot(xd);
 #endif
-            uint32_t talt = 0;
-            uint64_t wa = 0, wa2 = 0;
+            // (what the lanes that are not cross lanes hold in these is never looked at: no zeroing)
+            uint32_t talt;
+            uint64_t wa, wa2;
+            asm volatile("" : "=v"(talt), "=v"(wa), "=v"(wa2));
             // (lanes that are not cross lanes point at the sentinel slot: what they read there says "the candidate as read")
             const uint32_t qa = xd ? qx : ZZ_L1P_SELF;
             if (XD) {
@@ -150,7 +156,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     ZZ_C(13, 1);
                     v = *(volatile lds_u32*)&X->told[qa];
                 } while (ballot((v >> 16) != g) & XD);                   // (the scalar AND of two masks: no select, no second compare)
-                talt = xd ? (v & 0xFFFFu) : 0u;
+                talt = v & 0xFFFFu;
                 if (xd) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(talt, 1u), wa, wa2);      // (a gather costs the address path per lane)
             }
 
