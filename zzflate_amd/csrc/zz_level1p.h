@@ -16,10 +16,12 @@
 //   * a lane of g + 1 whose table read returns a position of block g ("cross lane", about a quarter of the lanes of text)
 //     has two likely candidates -- that position q if the walk of g visits it, else what the table held before block g
 //     under that hash (told_g[q], which block g's owner publishes, tagged with the block, as soon as it has settled its
-//     own cross lanes) -- and compares against both before the walk of g has finished. When it has, g's owner publishes
-//     per lane the highest VISITED lane of the block with that lane's hash (`win`), and one gathered byte per cross lane
-//     picks: q itself, nobody (the older entry), or -- rarely -- a lower lane of g, whose bytes are then fetched from the
-//     cache and compared on the spot (`R` below).
+//     own cross lanes) -- and asks for the bytes of both before the walk of g has finished. When it has, g's owner publishes
+//     per lane the highest VISITED lane of the block with that lane's hash (`win`, 64 = none), and one gathered byte per
+//     cross lane picks: q itself, nobody (the older entry), or -- 0.2 times per block of text -- a lower lane of g, whose
+//     bytes are then fetched from the cache; ONE comparison per lane follows, against the candidate that is the right one
+//     (`R` below; comparing against both in front of the barrier shortened R and lost 6 %: both parsers' intervals are
+//     critical, and so is every instruction in either).
 //   * repair of block g (skipped lanes restore the old entry, the highest visited lane per hash wins: the state the
 //     serial loop leaves) runs after block g + 1 has entered its positions, so it only touches slots that still hold
 //     a position of block g; a slot block g + 1 has overwritten is that block's to repair, from its resolved old entry.
@@ -28,13 +30,14 @@
 // with the HIGHEST position of the block under that hash): zz_ctx probes that once per device and falls back to
 // k_encode_l1 where it does not hold (zz_api.hip, lds_order_ok).
 //
-// Hand-over between the two parsers goes through 336 bytes of LDS (l1p_xch) and one s_barrier per block, which the
+// Hand-over between the two parsers goes through 468 bytes of LDS (l1p_xch) and one s_barrier per block, which the
 // emitter wavefront (the third of the workgroup: Adler-32, fixed-Huffman coding, bit packing -- as in k_encode_l1) joins.
-// LDS: 16,384 table + 512 ring + 512 token slots + 336 = 17,744 bytes <= 17,920: nine workgroups per CU, 27 wavefronts
-// (56 VGPRs, 65 SGPRs: the 27 fit whatever SIMDs the workgroups' wavefronts land on).
-// Measured (profiles/README.md, round 4): 1 GiB text 119 -> 123-124 GB/s, log lines 96 -> 117, the twelve-family mix
-// 102.5 -> 106; the optimistic bound of this shape (tools/pipe_probe.sh: no cross lanes, no exchange) is 159, and what the
-// exact cross-lane resolution costs is 17 % (the same kernel without it: 145-148 GB/s, wrong streams).
+// LDS: 16,384 table + 512 ring + 512 token slots + 468 = 17,876 bytes <= 17,920: nine workgroups per CU, 27 wavefronts
+// (61 VGPRs, 62 SGPRs: the 27 fit whatever SIMDs the workgroups' wavefronts land on).
+// Measured (profiles/README.md, round 4; DESIGN.md 4 has the steps): 1 GiB text 119 -> 140 GB/s, log lines in gzip 96 -> 116,
+// the twelve-family mix 102.5 -> 116; the optimistic bound of this shape (tools/pipe_probe.sh: no cross lanes, no
+// exchange) was 159 before the kernel existed, and the first exact form ran at 124: most of the way from there to 140 was
+// taking instructions out between the barriers, one A/B at a time.
 #pragma once
 #include "zz_level1.h"
 
