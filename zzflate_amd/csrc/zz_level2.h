@@ -706,19 +706,20 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
             // position of this block is probed), Brel = backRefEnd
             uint32_t np = (int32_t)(nextProbe - base) > 0 ? nextProbe - base : 0u;
             int32_t Brel = (int32_t)(B - base);
-            for (bool first = true;; first = false) {
-                uint32_t slow = 0;
-                if (first || np < 64) {
+            // (the scalar loop once in front and once at the bottom of the loop over what it cannot decide: the common case -- no
+            // such token in the block -- leaves through one test, where a loop around a single instance paid seven scalar
+            // instructions of flag bookkeeping behind every block's walk)
+            uint32_t slow = 0;
+            auto walk = [&]() {
                     uint32_t inf, t1, t2;
                     uint64_t tmp;
                     int32_t e;
                     asm volatile(
                         "1:\n\t"
                         "s_lshl_b64 %[tmp], -1, %[np]\n\t"
-                        "s_and_b64 %[tmp], %[tmp], %[A]\n\t"
-                        "s_ff1_i32_b64 %[e], %[tmp]\n\t"            // first candidate at or after np (-1: none)
-                        "s_cmp_lt_i32 %[e], 0\n\t"
-                        "s_cbranch_scc1 3f\n"
+                        "s_and_b64 %[tmp], %[tmp], %[A]\n\t"        // candidates at or after np; SCC = there is one
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_ff1_i32_b64 %[e], %[tmp]\n"
                         // plain lanes: two hops per taken branch (a taken branch costs about five scalar instructions)
                         "9:\n\t"
                         ZZ_L2_HOP "s_cbranch_scc0 10f\n\t"
@@ -761,8 +762,9 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                           [t1] "=&s"(t1), [t2] "=&s"(t2), [tmp] "=&s"(tmp), [e] "=&s"(e)
                         : [winfo] "v"(winfo), [A] "s"(Amask)
                         : "scc");
-                }
-                if (!slow) break;
+            };
+            walk();
+            while (__builtin_expect(slow != 0, 0)) {
                 // one token with a length of "8 or more" backward or "16 or more" forward, at lane np
                 const int e = (int)np;
                 const uint32_t qe = base + (uint32_t)e;
@@ -785,6 +787,8 @@ __device__ __forceinline__ void l2_token_pass(uint16_t* T, uint32_t* hb, const u
                 evmask |= 1ull << e;
                 slowmask |= 1ull << e;
                 np = (uint32_t)Brel + 1;                                                            // :424
+                slow = 0;
+                if (np < 64) walk();
             }
             B = base + (uint32_t)Brel;
             nextProbe = base + np;
