@@ -887,12 +887,14 @@ __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t*
                 // the match as the emission pass wants it: symbols and extra-bit values
                 tokens[ntok + mbcnt(evmask)] = ((sym - 257) << 23) | (lev << 18) | (bucket << 13) | dev;
                 // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
+                // (straight line for the one or two words nearly every match touches; a loop only for matches of more than 64 bytes)
                 const uint32_t last = ms + mlen - 1;
-                for (uint32_t wi = ms >> 6; wi <= (last >> 6); ++wi) {
-                    const uint32_t lo = wi == (ms >> 6) ? (ms & 63) : 0;
-                    const uint32_t hi = wi == (last >> 6) ? (last & 63) : 63;
-                    const uint64_t mask = ((hi == 63 ? 0ull : (1ull << (hi + 1))) - 1) & ~((1ull << lo) - 1);
-                    atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], (unsigned long long)mask);
+                const uint32_t w0 = ms >> 6, w1 = last >> 6;
+                const uint64_t from_lo = ~0ull << (ms & 63), to_hi = ~0ull >> (63u - (last & 63));
+                atomicOr((unsigned long long*)&covw[w0 & (ZZ_L2_WIN - 1)], (unsigned long long)(w1 == w0 ? (from_lo & to_hi) : from_lo));
+                if (w1 != w0) {
+                    atomicOr((unsigned long long*)&covw[w1 & (ZZ_L2_WIN - 1)], (unsigned long long)to_hi);
+                    for (uint32_t wi = w0 + 1; wi < w1; ++wi) atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], ~0ull);
                 }
                 atomicOr((unsigned long long*)&mstw[(ms >> 6) & (ZZ_L2_WIN - 1)], 1ull << (ms & 63));
                 hist_add(histP, sym);
