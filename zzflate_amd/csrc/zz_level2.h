@@ -858,8 +858,10 @@ __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t*
         // 1.66 M of the token pass's 1.83 M cycles per packet of text -- at issue priority 0 against the parser's 3 it was the one
         // the packet waited for. Where a block's matches are dense it takes the parser's priority for that block (text: 71.6 ->
         // 74.0 GB/s; always equal priorities: 73.9, but 69.1 against 70.3 on the twelve-family mix, where this costs 1 %).
-        if ((uint32_t)__builtin_popcountll(evmask) >= ZZ_L2_HELPER_DYNPRIO) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(0);
+        // (a one-armed test: with a priority in either arm the compiler's control-flow bookkeeping was eight instructions)
+        const uint32_t nmatch = uniform((uint32_t)__builtin_popcountll(evmask));
+        __builtin_amdgcn_s_setprio(0);
+        if (nmatch >= ZZ_L2_HELPER_DYNPRIO) __builtin_amdgcn_s_setprio(3);
         if (evmask) {
             const uint64_t slowmask = ((uint64_t)uniform(slot[67]) << 32) | uniform(slot[66]);
             const uint32_t Bentry = uniform(slot[68]);
@@ -900,7 +902,7 @@ __device__ __forceinline__ uint32_t l2_helper_pass(const uint32_t* hb, uint64_t*
                 hist_add(histP, sym);
                 hist_add(histP, 286 + bucket);
             }
-            ntok += (uint32_t)__builtin_popcountll(evmask);
+            ntok += nmatch;
         }
         // later matches start at >= base + 64 - 258: block (base>>6) - 5 cannot change any more
         if (i >= ZZ_L2_LAG) {
