@@ -127,6 +127,35 @@ def cpu_baseline(sample: bytes, level: int, fmt: int, P: int = 32768):
     return res
 
 
+def summarize_regions(times, steps):
+    """The contract's timed region -- exactly `steps` steps between two barriers -- measured `len(times)` times: the line's
+    ms_per_step (and `value`) come from the MEDIAN region, so that a short --steps (the driver passes 20: 0.15 s) does not hang
+    the headline on one sample of the clock; min and max say how far the regions spread. Pure arithmetic (tests/test_bench_host.py)."""
+    ts = sorted(times)
+    k = len(ts)
+    med = ts[k // 2] if k % 2 else 0.5 * (ts[k // 2 - 1] + ts[k // 2])
+    return {"repeats": k, "region_seconds_median": med, "ms_per_step": med / steps * 1e3,
+            "ms_per_step_min": ts[0] / steps * 1e3, "ms_per_step_max": ts[-1] / steps * 1e3, "timed_seconds_total": sum(ts)}
+
+
+def want_another_region(times, min_total=1.0, max_repeats=64):
+    """keep timing regions until they add up to a second (at least one, at most 64)"""
+    return len(times) < max_repeats and sum(times) < min_total
+
+
+def scalar_bound(scalar_insts, kernel_ms, cus=256, clock_ghz=2.4):
+    """roofline.scalar: a CU has ONE scalar unit, one instruction per cycle, for all its wavefronts (tools/ubench_scalar.hip:
+    0.92 per cycle measured with 32 waves on it). (SALU + branch instructions of a launch) / (CUs x clock x kernel time) = the
+    unit's mean issue rate per CU per cycle; `frac` is that against the measured ceiling."""
+    if not scalar_insts or not kernel_ms or kernel_ms <= 0:
+        return None
+    per_cycle = scalar_insts / (cus * clock_ghz * 1e9 * kernel_ms * 1e-3)
+    ceiling = 0.92
+    return {"bound": "scalar unit", "scalar_instructions": scalar_insts, "per_cu_per_cycle": round(per_cycle, 4), "ceiling_per_cu_per_cycle": ceiling,
+            "frac": round(per_cycle / ceiling, 4), "bound_ms": round(scalar_insts / (cus * clock_ghz * 1e9 * ceiling) * 1e3, 3),
+            "clock_ghz": clock_ghz, "cus": cus}
+
+
 def launch_ranks(n):
     """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment,
     as torch.distributed.run would set them) and wait for them. Children are separate processes started from a process
@@ -173,7 +202,7 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)     # (the timed region is then about a second: 120 x 8.4 ms)
+    ap.add_argument("--steps", type=int, default=60)      # (a timed region; regions are repeated until they add up to a second)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--mib", type=int, default=1024, help="input MiB per GPU")
@@ -195,6 +224,8 @@ def main():
     ap.add_argument("--gather-root", default="0", choices=["0", "rotate"], help="N > 1: '0' (default) = every step's stream is gathered "
                     "onto rank 0; 'rotate' = step i's onto rank i mod N (still ONE grouped send/recv per stream), so that a run of "
                     "streams is not capped by ONE GPU's seven inbound xGMI links")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region (exactly --steps steps) is repeated until the regions "
+                    "add up to this many seconds; 0 = one region (profiler passes)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-2 side measurement")
     ap.add_argument("--no-sequential", action="store_true", help="skip the threaded=false side measurement (64 MiB on one wavefront: seconds)")
@@ -400,15 +431,22 @@ def main():
         step()
     barrier()
     kernel_ms.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # The timed region: EXACTLY --steps steps between two barriers (+ synchronize), MAX over ranks -- and that region again until
+    # the regions add up to a second (every rank sees the same reduced times, so every rank stops at the same repeat).
+    region_times = []
+    while want_another_region(region_times, args.min_seconds):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if multi:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        region_times.append(dt)
+    regions = summarize_regions(region_times, args.steps)
+    dt = regions["region_seconds_median"]
 
     # ---- validation of what was just measured (untimed) ----------------------------------------------------------
     # every packet this rank produced in the last step is inflated on the device and compared with its input
@@ -595,7 +633,7 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/collect_profiles.sh; counters
         # cannot be read inside this run). profiles/traffic.json records which sources it was measured on: it is only
         # reported while those are the sources this run was built from.
-        traffic, traffic_src, insts = None, None, None
+        traffic, traffic_src, insts, tj_scalar = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -608,6 +646,7 @@ def main():
                 if tj.get("source_sha256") == hsh.hexdigest():
                     traffic = tj.get(f"level{args.level}_{args.gen}_{args.mib}MiB")
                     insts = tj.get(f"instructions_level{args.level}_{args.gen}_{args.mib}MiB")
+                    tj_scalar = tj.get(f"scalar_instructions_level{args.level}_{args.gen}_{args.mib}MiB")
                     traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')}"
                 else:
                     traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')} is stale (kernel sources changed since): not reported"
@@ -619,8 +658,12 @@ def main():
         # profile pass as `traffic`) x 5 cycles / (resident wavefronts x clock): what the kernel would take if every resident
         # wavefront issued flat out; frac = bound_ms / kernel_ms.
         issue = None
+        # which level-1 kernel ran: asked of the library (ZZFLATE_L1_KERNEL=classic and a negative LDS-order verdict both give k_encode_l1)
+        l1_two = args.level == 1 and not args.warm and (not hasattr(zz.lib, "zz_debug_l1_kernel") or zz.lib.zz_debug_l1_kernel(ctx._h) == 2)
+        l1_kernel = "k_encode_l1w" if args.warm else ("k_encode_l1p" if l1_two else "k_encode_l1")
+        scal = tj_scalar if (args.level == 1 and l1_two) or args.level in (2, 3) else None
         if insts and kms > 0 and args.level >= 1:
-            resident = 256 * (8 if args.level >= 4 else 9) * (3 if args.level == 1 else 2)     # level 1: two parsers + the emitter per packet (k_encode_l1p)
+            resident = 256 * (8 if args.level >= 4 else 9) * (3 if l1_two else 2)     # k_encode_l1p: two parsers + the emitter per packet
             cpi, ghz = 5.0, 2.4
             bound_ms = insts * cpi / (resident * ghz * 1e9) * 1e3
             issue = {"bound": "issue", "instructions": insts, "cycles_per_instruction": cpi, "resident_wavefronts": resident,
@@ -633,6 +676,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
+            "repeats": regions["repeats"],
+            "ms_per_step_min_max": [round(regions["ms_per_step_min"], 3), round(regions["ms_per_step_max"], 3)],
+            "timed_seconds_total": round(regions["timed_seconds_total"], 3),
             "higher_is_better": True,
             "scaling": "weak",
             "backend": (("rccl" if backend == "nccl" else backend) + f" (torch.distributed {backend}, world size {dist.get_world_size()})") if multi else None,
@@ -650,11 +696,11 @@ def main():
             "exchange": exchange if multi else None,
             "roofline": {
                 "bound": "hbm", "kernel": ("k_l6_matches + k_encode_l2_t" if args.level >= 4 else "k_encode_l2_t" if args.level >= 2
-                                           else ("k_encode_l1w" if args.warm else "k_encode_l1p") if args.level == 1 else "k_encode_l0"),
+                                           else l1_kernel if args.level == 1 else "k_encode_l0"),
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(kms, 4), "traffic": traffic,
-                "traffic_source": traffic_src, "issue": issue,
+                "traffic_source": traffic_src, "issue": issue, "scalar": scalar_bound(scal, kms),
             },
             "cpu_baseline": cpu,
             "check": check,

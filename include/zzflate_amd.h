@@ -211,6 +211,9 @@ int zz_generate_host(int kind, uint64_t seed, uint64_t first_byte, uint8_t* buf,
 
 const char* zz_last_error(void);
 const char* zz_version(void);
+/* the compile-time experiment switches this binary carries, space-separated; "" for the product build (some of them write
+ * deliberately wrong streams for timing runs: a deployment can assert on "") */
+const char* zz_build_flags(void);
 
 #ifdef __cplusplus
 }

@@ -1093,6 +1093,9 @@ uint64_t zzo_encode_ranges(uint8_t* dest, uint64_t cap, const uint8_t* src, uint
     memcpy(dest, h, (size_t)hl);
     uint64_t total = (uint64_t)hl;
     const uint64_t step = (n + count - 1) / count;            /* :70 */
+    /* D10: with count near sqrt(n) or above, divideInRanges' trailing boundaries lie past n (the reference then reads past its
+     * input: undefined, nothing to restate) -- refused, as zz_encode_ranges_device refuses it */
+    if ((uint64_t)(count - 1) * step >= n) return ZZO_ERROR;
     for (uint32_t k = 0; k < count; ++k) {
         const uint64_t off = step * k;                        /* :73 */
         const uint64_t end = k + 1 == count ? n : step * (k + 1);   /* :75 */

@@ -67,6 +67,13 @@ class Oracle:
         assert n != 0xFFFFFFFFFFFFFFFF
         return b.raw[:n]
 
+    def encode_ranges_raw(self, d, fmt, lvl, count):
+        """the same, None where the restatement refuses the split (ranges that would start past the input's end, D10)"""
+        cap = 2 * len(d) + 4096 + 16 * count
+        b = ctypes.create_string_buffer(cap)
+        n = self.L.zzo_encode_ranges(b, cap, d, len(d), fmt, lvl, count)
+        return None if n == 0xFFFFFFFFFFFFFFFF else b.raw[:n]
+
     def encode(self, d, fmt, lvl, cap=None):
         """zzo_encode into a destination of `cap` bytes (default: roomy). At level 1 the capacity decides the block
         lengths (encoder.cpp:331-337); like the reference, the restatement silently leaves a truncated stream when the

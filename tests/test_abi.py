@@ -94,6 +94,21 @@ def test_lds_order_guard_hook_answers_without_a_device():
         L.zz_debug_force_lds_order(ctypes.c_int(-1))
 
 
+def test_shipped_library_carries_no_experiment_switch():
+    """zz_level1.h / zz_level1p.h hold timing experiments behind macros that write WRONG streams (ZZ_L1_PIPE_PROBE, ZZ_L1P_X_*),
+    cycle stamps (ZZ_PROF) and the test build's ZZ_ST_ALWAYS_CAREFUL: the library the package loads must be built without any
+    of them, and the test build must own up to its one."""
+    L = ctypes.CDLL(zz._build.LIB)
+    L.zz_build_flags.restype = ctypes.c_char_p
+    assert L.zz_build_flags() == b"", L.zz_build_flags()
+    assert zz.lib.zz_build_flags() == b"" or os.environ.get("ZZFLATE_AMD_LIB"), zz.lib.zz_build_flags()
+    careful = zz._build.CAREFUL_LIB
+    if os.path.exists(careful):
+        C = ctypes.CDLL(careful)
+        C.zz_build_flags.restype = ctypes.c_char_p
+        assert C.zz_build_flags().split() == [b"ZZ_ST_ALWAYS_CAREFUL"]
+
+
 def test_product_does_not_touch_oracle():
     """The shipped package must not import, link or open anything under oracle/."""
     pkg = os.path.join(ROOT, "zzflate_amd")

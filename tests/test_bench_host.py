@@ -67,3 +67,26 @@ def test_profile_summaries_keep_template_instantiations_apart():
     assert m.short('"zz::k_encode_l1(zz_packet_params)"') == "zz::k_encode_l1"
     assert m.short('"void zz::k_l6_matches<8>(zz::zz_l6m_params)"') == "zz::k_l6_matches<8>"
     assert m.short("k_generate(int, unsigned long, unsigned long, unsigned char*, unsigned long)") == "k_generate"
+
+
+def test_timed_regions_are_repeated_to_a_second_and_summarised_by_their_median():
+    """bench.py times the contract's region (exactly --steps steps) again and again until the regions add up to a second; the
+    line's ms_per_step and value come from the median region, min and max ride along."""
+    times = []
+    while bench.want_another_region(times):
+        times.append(0.153)                      # the driver's --steps 20 at 7.65 ms per step
+    assert len(times) == 7 and sum(times) >= 1.0
+    assert not bench.want_another_region([1.2]) and bench.want_another_region([])
+    assert not bench.want_another_region([0.001] * 64)           # bounded
+    r = bench.summarize_regions([0.160, 0.150, 0.155, 0.152, 0.300], 20)
+    assert r["repeats"] == 5 and abs(r["ms_per_step"] - 7.75) < 1e-9
+    assert abs(r["ms_per_step_min"] - 7.5) < 1e-9 and abs(r["ms_per_step_max"] - 15.0) < 1e-9
+    r = bench.summarize_regions([0.2, 0.1], 10)
+    assert abs(r["ms_per_step"] - 15.0) < 1e-9 and r["repeats"] == 2
+
+
+def test_scalar_unit_bound_arithmetic():
+    """roofline.scalar: (SALU + branch) / (256 CUs x 2.4 GHz x kernel time) per CU per cycle against the measured 0.92"""
+    b = bench.scalar_bound(2_660_000_000, 7.34)
+    assert abs(b["per_cu_per_cycle"] - 2.66e9 / (256 * 2.4e9 * 7.34e-3)) < 1e-4 and 0.6 < b["frac"] < 0.7
+    assert bench.scalar_bound(None, 7.0) is None and bench.scalar_bound(1, 0) is None

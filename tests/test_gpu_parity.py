@@ -592,6 +592,60 @@ def test_lds_order_guard_refuses_and_level1_falls_back(gpu, oracle, corpus):
     ctx.set_warm_window(0)
 
 
+def test_lds_order_violation_seen_by_the_kernel_reruns_the_call(gpu, oracle, corpus):
+    """k_encode_l1p checks the invariant it stands on as it runs (the slot must end up with the HIGHEST lane's entry: zz_level1p.h
+    P2) and the warm window's pre-hash checks the same property on its last store per trip (level 1) or on a canary (levels 2, 3).
+    A violation (forced here through the kernel's own report path: zz_packet_params::dbg_viol) must (a) take the device's verdict
+    away, (b) run the level-1 CALL again on the one-wavefront kernel -- the stream handed out is the oracle's --, (c) fail a
+    warm-window call with ZZ_E_UNSUPPORTED and a message instead of handing out a stream that may not be the defined one."""
+    import torch
+    ctx = zz.Context(0)
+    d = corpus["lcet10.txt"] + corpus["ptt5"][:200000]
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    cap = zz.bound(len(d), 0, 1, 32768)
+    dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+
+    def enc(lvl, fmt=0):
+        w = ctx.encode(src, len(d), dst, cap, fmt, lvl, 32768)
+        assert ctx.verify_last() == (0, None)
+        return dst[:w].cpu().numpy().tobytes()
+    try:
+        assert zz.lib.zz_debug_lds_order_verdict(0) == 1 and zz.lib.zz_debug_l1_kernel(ctx._h) == 2
+        want = oracle.encode_packets(d, 1, 1, 32768)
+        assert enc(1, 1) == want                               # no violation: k_encode_l1p, verdict kept
+        assert zz.lib.zz_debug_l1_kernel(ctx._h) == 2
+        zz.lib.zz_debug_force_lds_violation(1)
+        assert enc(1, 1) == want                               # violation reported by the kernel: the call ran again, same bytes
+        assert zz.lib.zz_debug_lds_order_verdict(0) == 0 and zz.lib.zz_debug_l1_kernel(ctx._h) == 1
+        assert enc(1, 1) == want                               # and every later call takes k_encode_l1 straight away
+        with pytest.raises(zz.ZzFlateError) as e:              # the modes without a fallback are refused from here on
+            ctx.set_warm_window(4096)
+        assert e.value.code == -5
+        # the asynchronous form: the rerun happens in zz_encode_finish
+        zz.lib.zz_debug_reset_lds_order(0)
+        assert zz.lib.zz_debug_lds_order_verdict(0) == 1
+        zz.lib.zz_debug_force_lds_violation(1)
+        ctx.encode_async(src, len(d), dst, cap, 1, 1, 32768)
+        w = ctx.finish()
+        assert dst[:w].cpu().numpy().tobytes() == want and zz.lib.zz_debug_lds_order_verdict(0) == 0
+        # warm window, levels 1 and 2: no other form exists, the call fails loudly
+        for lvl in (1, 2):
+            zz.lib.zz_debug_reset_lds_order(0)
+            ctx.set_warm_window(32768)
+            assert enc(lvl) == oracle.encode_packets(d, 0, lvl, 32768, 32768)
+            zz.lib.zz_debug_force_lds_violation(1)
+            with pytest.raises(zz.ZzFlateError) as e:
+                enc(lvl)
+            assert e.value.code == -5 and "lane order" in str(e.value), lvl
+            ctx.set_warm_window(0)
+            assert zz.lib.zz_debug_lds_order_verdict(0) == 0
+    finally:
+        zz.lib.zz_debug_force_lds_violation(0)
+        zz.lib.zz_debug_reset_lds_order(0)
+        ctx.set_warm_window(0)
+    assert zz.lib.zz_debug_lds_order_verdict(0) == 1 and zz.lib.zz_debug_l1_kernel(ctx._h) == 2
+
+
 def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
     """levels 4, 5, 6 (off unless switched on) = hash chains of depth 2 / 4 / 8 over a window of 8 / 32 /
     32 KiB, one-step lazy matching, package-merge code lengths (zz_level6.h). Bit-exact with the oracle's definition

@@ -93,3 +93,33 @@ def test_host_entry_point_with_ZZFLATE_RANGES(monkeypatch, oracle, corpus):
     assert got == oracle.encode_packets(d, 0, 1)
     monkeypatch.delenv("ZZFLATE_RANGES")
     assert zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, 2, True)) == oracle.encode_packets(d, 0, 2)
+
+
+def test_counts_whose_ranges_would_start_past_the_input_are_refused(oracle):
+    """(count - 1) * ceil(n / count) >= n: divideInRanges (zzflate.cpp:67-78) would cut ranges that start past the input's end (the
+    reference reads out of bounds there, D10). The device entry point refuses them with ZZ_E_ARG and says why, before anything is
+    launched; every other count up to 256 equals the oracle; the host entry point falls through to packet mode."""
+    ctx = zz.Context(0)
+    for count in (128, 192, 256):
+        ns = range(100 * count, 100 * count + 400)
+        bad = [n for n in ns if (count - 1) * (-(-n // count)) >= n]
+        good = [n for n in ns if (count - 1) * (-(-n // count)) < n]
+        for n in bad[:2] + bad[-1:]:
+            d = synth("words", n, count)
+            for lvl in (0, 2, 3):
+                with pytest.raises(zz.ZzFlateError) as e:
+                    run(ctx, d, 0, lvl, count)
+                assert e.value.code == -4 and "count too large" in str(e.value), (count, n, lvl)
+        for n in good[:1] + good[-1:]:
+            d = synth("words", n, count)
+            for lvl in (0, 2, 3):
+                assert run(ctx, d, 0, lvl, count) == oracle.encode_ranges(d, 0, lvl, count), (count, n, lvl)
+
+
+def test_host_entry_point_serves_what_the_split_cannot_in_packet_mode(monkeypatch, oracle):
+    # ZZFLATE_RANGES with a count the split cannot take (or above 4096): the call is served in packet mode, not failed
+    d = synth("words", 20000, 5)
+    for count in ("192", "5000"):
+        monkeypatch.setenv("ZZFLATE_RANGES", count)
+        for lvl in (0, 2):
+            assert zz.ZzFlateEncode(d, zz.Config(zz.Format.Zlib, lvl, True)) == oracle.encode_packets(d, 0, lvl), (count, lvl)

@@ -37,6 +37,17 @@ def test_level1_kernels_fit_nine_workgroups_per_cu_without_scratch(report):
     assert re.search(r"k_encode_l1E16zz_packet_params: 0 scratch_store, 0 scratch_load", report)
 
 
+def test_two_parser_level1_kernel_keeps_nine_workgroups_of_three_wavefronts(report):
+    """k_encode_l1p (the headline kernel): three wavefronts per packet, nine packets per CU = 27 wavefronts, seven on one SIMD at
+    worst -- 512 / 7 = 73 registers, so at most 72 VGPRs; LDS in nine shares of the CU's 160 KiB at the allocation granule; no
+    scratch. 44 bytes of LDS are what stands between nine workgroups and eight."""
+    u = usage(report, "_ZN2zz12k_encode_l1pE16zz_packet_params")
+    lds = int(u["LDS Size [bytes/block]"])
+    assert -(-lds // 512) * 512 * 9 <= 160 * 1024, lds                    # allocated in 512-byte granules (17,920 = 35 of them)
+    assert int(u["VGPRs"]) <= 72 and int(u["ScratchSize [bytes/lane]"]) == 0 and int(u["VGPRs Spill"]) == 0
+    assert re.search(r"k_encode_l1pE16zz_packet_params: 0 scratch_store, 0 scratch_load", report)
+
+
 def test_level2_kernel_scratch_stays_out_of_the_block_loops(report):
     u = usage(report, "_ZN2zz13k_encode_l2_tILj0ELb0EEEvNS_12zz_l2_paramsE")
     assert int(u["LDS Size [bytes/block]"]) * 9 <= 160 * 1024 and int(u["VGPRs"]) <= 96

@@ -46,3 +46,24 @@ def test_reference_live_with_this_machines_count(oracle, ref):
     d = synth("words", 200000, 11)
     for lvl in (0, 2, 3):
         assert ref.encode(d, 0, lvl, threaded=1) == oracle.encode_ranges(d, 0, lvl, count), lvl
+
+
+def test_counts_whose_ranges_would_start_past_the_input_are_refused(oracle):
+    """divideInRanges (zzflate.cpp:67-78) puts boundary i at ceil(n / count) * i: with count near sqrt(n) or above, the trailing
+    ranges start at or past the input's end (the reference reads out of bounds there). The restatement refuses
+    exactly those -- (count - 1) * ceil(n / count) >= n -- and nothing else."""
+    def splits(n, count):
+        return (count - 1) * (-(-n // count)) < n
+    assert not splits(20000, 192) and not splits(12801, 128)            # the advisor's examples
+    for count in (128, 192, 256):
+        bad = [n for n in range(100 * count, 100 * count + 400) if not splits(n, count)]
+        good = [n for n in range(100 * count, 100 * count + 400) if splits(n, count)]
+        assert bad and good
+        for n in bad[:2] + bad[-1:]:
+            d = synth("words", n, count)
+            for lvl in (0, 2, 3):
+                assert oracle.encode_ranges_raw(d, 0, lvl, count) is None, (count, n, lvl)
+        for n in good[:1] + good[-1:]:
+            d = synth("words", n, count)
+            for lvl in (0, 2, 3):
+                assert zlib.decompress(oracle.encode_ranges(d, 0, lvl, count)) == d, (count, n, lvl)

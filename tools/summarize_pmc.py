@@ -75,6 +75,12 @@ def main():
         return int(sum(c[k] for k in keys)) if all(k in c for k in keys) else None
     traffic["instructions_level1_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l1p")
     traffic["instructions_level2_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l2_t<0u, false>")
+    # the CU's one scalar unit: SALU + branch instructions per launch (bench.py roofline.scalar)
+    def scalar(run, kern):
+        c = out.get(run, {}).get(kern, {})
+        return int(c["SQ_INSTS_SALU"] + c["SQ_INSTS_BRANCH"]) if "SQ_INSTS_SALU" in c and "SQ_INSTS_BRANCH" in c else None
+    traffic["scalar_instructions_level1_text_1024MiB"] = scalar("sq_l1", "zz::k_encode_l1p")
+    traffic["scalar_instructions_level2_text_1024MiB"] = scalar("sq_l1", "zz::k_encode_l2_t<0u, false>")
     traffic["git_sha"] = a.git_sha
     traffic["source_sha256"] = source_hash()
     json.dump(traffic, open(os.path.join(a.dest, "traffic.json"), "w"), indent=1)

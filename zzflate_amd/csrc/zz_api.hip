@@ -5,6 +5,7 @@
 // There is no CPU encode path in this library: every byte of DEFLATE output is produced by the HIP
 // kernels, and every entry point fails with ZZ_E_HIP when no device is usable.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -34,6 +35,32 @@ static thread_local std::string g_err;
 static void set_err(const std::string& s) { g_err = s; }
 extern "C" const char* zz_last_error(void) { return g_err.c_str(); }
 extern "C" const char* zz_version(void) { return "zzflate_amd 0.1 (gfx950)"; }
+// Compile-time switches this binary was built with, as a space-separated list; "" for the product build. The first three write
+// WRONG STREAMS (timing experiments: tools/pipe_probe.sh, tools/units_probe.sh); ZZ_PROF adds cycle stamps; the last one is the
+// test build libzzflate_amd_careful.so. tests/test_abi.py holds the shipped library to "".
+extern "C" const char* zz_build_flags(void)
+{
+    return ""
+#ifdef ZZ_L1_PIPE_PROBE
+        " ZZ_L1_PIPE_PROBE"
+#endif
+#ifdef ZZ_L1P_X_NOCROSS
+        " ZZ_L1P_X_NOCROSS"
+#endif
+#ifdef ZZ_L1P_X_NOEMIT
+        " ZZ_L1P_X_NOEMIT"
+#endif
+#ifdef ZZ_PROF
+        " ZZ_PROF"
+#endif
+#ifdef ZZ_L1_EMIT_PRIO
+        " ZZ_L1_EMIT_PRIO"
+#endif
+#ifdef ZZ_ST_ALWAYS_CAREFUL
+        " ZZ_ST_ALWAYS_CAREFUL"
+#endif
+        ;
+}
 
 #define HIPCHK(expr)                                                                     \
     do {                                                                                 \
@@ -70,7 +97,13 @@ struct zz_ctx {
     uint32_t* d_work = nullptr;          // level 2: packet counter of the persistent workgroups
     uint64_t* d_log = nullptr; uint64_t log_cap_bytes = 0;   // sequential stream, callback form: EnsureOutputLength log
     // a call that has been enqueued but not waited for (zz_encode_device_async .. zz_encode_finish)
-    struct { bool active = false; hipStream_t st = nullptr; uint32_t npk = 0; int level = 0; bool whole = false; } pend;
+    struct {
+        bool active = false; hipStream_t st = nullptr; uint32_t npk = 0; int level = 0; bool whole = false;
+        // the call itself, for the rerun behind a run-time LDS-order violation (encode_finish)
+        bool order_checked = false;          // the launch relied on the LDS's lane order and checked it in the kernel
+        const uint8_t* d_src = nullptr; uint64_t n = 0, halo = 0; bool last_is_final = false; uint8_t* d_dst = nullptr; uint64_t cap = 0;
+        int format = 0, cks_kind = 0, level_asked = 0; uint32_t P = 0; uint32_t warm = 0;
+    } pend;
     uint32_t* h_err = nullptr;           // pinned: the kernels' sticky error word
     uint32_t warm = 0;                   // levels >= 1: warm window in bytes (0 = cold packets, the reference's threaded mode)
     bool extended = false;               // levels 4..6 accepted (beyond the reference)
@@ -120,6 +153,7 @@ extern "C" uint64_t zz_bound(uint64_t n, int format, int level, uint32_t P)
     return header_len(format) + npk * per + trailer_len(format) + 16;
 }
 
+static bool lds_order_ok(int device);
 extern "C" void zz_ctx_destroy(zz_ctx* c);
 extern "C" int zz_ctx_create(int device, zz_ctx** out)
 {
@@ -147,6 +181,7 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipHostMalloc((void**)&c->h_err, 4 * sizeof(uint32_t), hipHostMallocDefault));
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
+        (void)lds_order_ok(device);          // the probe, once per device, HERE: the launch sites only read its cached verdict
         return ZZ_OK;
     }();
     if (rc) { zz_ctx_destroy(c); return rc; }                            // nothing allocated so far is left behind
@@ -313,31 +348,54 @@ extern "C" int zz_debug_lds_atomic_order(zz_ctx* c, uint32_t trials, unsigned lo
 // refused with ZZ_E_UNSUPPORTED and level 1 runs its one-wavefront kernel (k_encode_l1, which asks the LDS for nothing of the
 // kind); levels 0..3 with cold packets never depend on it. zz_debug_force_lds_order lets a test take the refusal path.
 static std::mutex g_order_mu;
-static int g_order_verdict[64];            // per device: 0 unknown, 1 holds, -1 does not
-static int g_order_forced = -1;            // -1: probe; 0 / 1: the verdict every device gets (tests)
-extern "C" void zz_debug_force_lds_order(int verdict) { std::lock_guard<std::mutex> lk(g_order_mu); g_order_forced = verdict < 0 ? -1 : (verdict ? 1 : 0); }
+static std::atomic<int> g_order_verdict[64];     // per device: 0 unknown, 1 holds, -1 does not
+static std::atomic<int> g_order_forced{-1};      // -1: probe; 0 / 1: the verdict every device gets (tests)
+static std::atomic<int> g_force_violation{0};    // tests: the next level-1 / warm-window launches report a violated order (bit 4 of the error word)
+extern "C" void zz_debug_force_lds_order(int verdict) { g_order_forced.store(verdict < 0 ? -1 : (verdict ? 1 : 0)); }
+// (not part of the public header) n > 0: the next n encode launches that check the order in the kernel (k_encode_l1p, the warm window's
+// pre-hash) behave as if they had seen it violated -- the test of the rerun / refusal path behind that check
+extern "C" void zz_debug_force_lds_violation(int launches) { g_force_violation.store(launches < 0 ? 0 : launches); }
+// (not part of the public header) forget a device's verdict (tests put back what a forced violation flipped)
+extern "C" void zz_debug_reset_lds_order(int device) { if (device >= 0 && device < 64) g_order_verdict[device].store(0); }
+// Runs the probe where the device has no verdict yet. Blocking (allocation, a kernel on the null stream, a synchronous copy): called
+// from zz_ctx_create and the setters, never from an enqueue-only entry point -- the launch sites read the cached verdict
+// (lds_order_cached: one atomic load, no HIP call, nothing that would break a stream capture or sit between two timing events).
 static bool lds_order_ok(int device)
 {
-    std::lock_guard<std::mutex> lk(g_order_mu);
-    if (g_order_forced >= 0) return g_order_forced == 1;
+    const int forced = g_order_forced.load();
+    if (forced >= 0) return forced == 1;
     if (device < 0 || device >= 64) return false;
-    if (g_order_verdict[device] == 0) {
-        unsigned long long bad = 1, *d = nullptr;
-        int prev = 0;
-        bool ran = hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess && hipMalloc(&d, sizeof(bad)) == hipSuccess;
-        if (ran) {
-            ran = hipMemset(d, 0, sizeof(bad)) == hipSuccess;
+    if (g_order_verdict[device].load() == 0) {
+        std::lock_guard<std::mutex> lk(g_order_mu);
+        if (g_order_verdict[device].load() == 0) {
+            unsigned long long bad = 1, *d = nullptr;
+            int prev = 0;
+            bool ran = hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess && hipMalloc(&d, sizeof(bad)) == hipSuccess;
             if (ran) {
-                hipLaunchKernelGGL(k_lds_order_probe, dim3(512), dim3(1024), 0, 0, 0xC0FFEEu ^ (uint32_t)device, 4u, d);   // 12.6 M checks, < 1 ms
-                ran = hipGetLastError() == hipSuccess && hipMemcpy(&bad, d, sizeof(bad), hipMemcpyDeviceToHost) == hipSuccess;
+                ran = hipMemset(d, 0, sizeof(bad)) == hipSuccess;
+                if (ran) {
+                    hipLaunchKernelGGL(k_lds_order_probe, dim3(512), dim3(1024), 0, 0, 0xC0FFEEu ^ (uint32_t)device, 4u, d);   // 12.6 M checks, < 1 ms
+                    ran = hipGetLastError() == hipSuccess && hipMemcpy(&bad, d, sizeof(bad), hipMemcpyDeviceToHost) == hipSuccess;
+                }
+                (void)hipFree(d);
+                (void)hipSetDevice(prev);
             }
-            (void)hipFree(d);
-            (void)hipSetDevice(prev);
+            if (!ran) (void)hipGetLastError();
+            g_order_verdict[device].store((ran && bad == 0) ? 1 : -1);
         }
-        g_order_verdict[device] = (ran && bad == 0) ? 1 : -1;
     }
-    return g_order_verdict[device] == 1;
+    return g_order_verdict[device].load() == 1;
 }
+// the verdict as the launch sites read it: every context's creation has run the probe for its device
+static inline bool lds_order_cached(int device)
+{
+    const int forced = g_order_forced.load(std::memory_order_relaxed);
+    if (forced >= 0) return forced == 1;
+    return device >= 0 && device < 64 && g_order_verdict[device].load(std::memory_order_relaxed) == 1;
+}
+// A kernel saw the order violated at run time (bit 4 of the error word: zz_level1p.h P2, zz_level1.h warm_prehash): the device loses
+// its verdict for the rest of the process -- level 1 runs k_encode_l1 from here on, warm windows and extended levels are refused.
+static void lds_order_revoke(int device) { if (device >= 0 && device < 64) g_order_verdict[device].store(-1); }
 // (not part of the public header) the verdict for a device: 1 holds, 0 does not
 extern "C" int zz_debug_lds_order_verdict(int device) { return lds_order_ok(device) ? 1 : 0; }
 // diagnostic builds only (not part of the public header): read and clear the per-phase cycle counters
@@ -412,13 +470,25 @@ static int ensure_workspace(zz_ctx* c, int level, uint64_t npk, uint32_t stride,
     return ZZ_OK;
 }
 
+// ZZFLATE_L1_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet (k_encode_l1) instead of the two of k_encode_l1p;
+// the streams are the same
+static bool l1_classic()
+{
+    static const bool classic = [] { const char* e = getenv("ZZFLATE_L1_KERNEL"); return e && !strcmp(e, "classic"); }();
+    return classic;
+}
+// (not part of the public header) which level-1 kernel a cold packet-mode call on this context would launch now: 2 = k_encode_l1p
+// (two parsing wavefronts), 1 = k_encode_l1 (ZZFLATE_L1_KERNEL=classic, or the device's LDS-order verdict is negative)
+extern "C" int zz_debug_l1_kernel(const zz_ctx* c) { return (c && !l1_classic() && lds_order_cached(c->device)) ? 2 : 1; }
 // The common pipeline. with_container: write header/trailer (whole stream) or not (shard).
 static int encode_finish(zz_ctx* c, zz_result* host_res);
 // `host_res` == nullptr: enqueue only (zz_encode_device_async); the caller collects with encode_finish.
 static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t halo, bool last_is_final,
                          uint8_t* d_dst, uint64_t cap, int format, int cks_kind, bool with_container, int level,
-                         uint32_t P, hipStream_t st, zz_result* host_res)
+                         uint32_t P, hipStream_t st, zz_result* host_res, bool one_parser = false)
 {
+    const int level_asked = level;
+    bool order_checked = false;
     if (c->pend.active) { set_err("a call enqueued with zz_encode_device_async has not been finished on this context"); return ZZ_E_ARG; }
     // Levels 4..6 are beyond the reference (which rejects them, zzflate.cpp:201,230) and only exist when switched on:
     // hash chains of depth 2 / 4 / 8 over a window of 8 / 32 / 32 KiB in front of every packet, lazy matching, package-merge
@@ -466,6 +536,15 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         pp.src = d_src; pp.n = n; pp.halo = halo; pp.packet_size = P; pp.npk = npk;
         pp.last_is_final = last_is_final ? 1 : 0; pp.cks_kind = cks_kind; pp.warm = warm;
         pp.slots = c->slots; pp.slot_stride = stride; pp.sizes = c->sizes; pp.cks = c->cks; pp.err = c->d_err; pp.prof = c->d_prof; pp.tail = c->d_tail;
+        pp.dbg_viol = 0;
+        // does this launch rely on the LDS's lane order (and check it as it goes: error bit 4)? k_encode_l1p; the warm window's pre-hash
+        const bool l1p = level == 1 && !warm && !one_parser && !l1_classic() && lds_order_cached(c->device);
+        order_checked = l1p || (warm != 0 && xdepth == 0);
+        if (order_checked) {
+            int left = g_force_violation.load();
+            while (left > 0 && !g_force_violation.compare_exchange_weak(left, left - 1)) {}
+            if (left > 0) pp.dbg_viol = 1;
+        }
 
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, st));   // the CRC-32 pass of the gzip container is part of the timed work
         if (cks_kind == ZZ_CKS_CRC) {
@@ -489,11 +568,8 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);      // (what reads past the shard's end reads this)
             // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-            // ZZFLATE_L1_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet (k_encode_l1) instead of the two of
-            // k_encode_l1p; the streams are the same
-            static const bool classic = [] { const char* e = getenv("ZZFLATE_L1_KERNEL"); return e && !strcmp(e, "classic"); }();
             if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
-            else if (classic || !lds_order_ok(c->device)) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            else if (!l1p) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
             else hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
         } else {
             hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);
@@ -522,6 +598,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         v.l0_stride = (uint32_t)l0_packet_bytes(P, false);
     }
     c->pend.active = true; c->pend.st = st; c->pend.npk = npk; c->pend.level = level; c->pend.whole = with_container;
+    c->pend.order_checked = order_checked;
+    c->pend.d_src = d_src; c->pend.n = n; c->pend.halo = halo; c->pend.last_is_final = last_is_final; c->pend.d_dst = d_dst; c->pend.cap = cap;
+    c->pend.format = format; c->pend.cks_kind = cks_kind; c->pend.level_asked = level_asked; c->pend.P = P; c->pend.warm = warm;
     if (!host_res) return ZZ_OK;
     return encode_finish(c, host_res);
 }
@@ -532,6 +611,22 @@ static int encode_finish(zz_ctx* c, zz_result* host_res)
     c->pend.active = false;
     HIPCHK(hipStreamSynchronize(c->pend.st));
     *host_res = *c->h_res;
+    if (c->h_err[0] & 4u) {
+        // A kernel of this call saw the LDS leave a LOWER lane's store in a slot that a higher lane of the same instruction wrote too
+        // (zz_level1p.h P2; zz_level1.h warm_prehash): what it wrote is a valid stream, but not necessarily the reference's. The
+        // device loses its verdict; level 1 runs the CALL again on the one-wavefront kernel, which asks the LDS for nothing of the
+        // kind (same bytes as k_encode_l1p where that one is right); a warm window has no such form and is refused from here on.
+        lds_order_revoke(c->device);
+        if (!c->pend.order_checked) { set_err("internal: LDS-order violation reported by a kernel that does not check it"); return ZZ_E_HIP; }
+        if (c->pend.warm) {
+            set_err("warm window: this device's LDS served equal addresses out of lane order during the call (checked in the kernel); "
+                    "the stream is valid DEFLATE but not the defined one -- warm windows are refused on this device from now on");
+            return ZZ_E_UNSUPPORTED;
+        }
+        const auto q = c->pend;
+        return encode_common(c, q.d_src, q.n, q.halo, q.last_is_final, q.d_dst, q.cap, q.format, q.cks_kind, q.whole, q.level_asked, q.P,
+                             q.st, host_res, true);
+    }
     if (c->h_err[0]) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
     if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
     if (c->pend.npk) { c->last.stream_bytes = host_res->stream_bytes; c->have_last = true; }
@@ -743,6 +838,13 @@ static int encode_stream(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
 // dependency chain, and longer than the packet kernels' 16-bit positions allow), so it is a compatibility mode like the
 // sequential stream. Levels 0, 2, 3: at level 1 the reference's threaded stream is invalid (the block
 // lengths follow from the room, destLen / count per range, and the joined stream does not inflate), so there is nothing to equal.
+// every range of the reference's split starts inside the input: (count - 1) * ceil(n / count) < n
+static bool ranges_split_ok(uint64_t n, uint32_t count)
+{
+    if (count == 0) return false;
+    const uint64_t step = (n + count - 1) / count;
+    return (uint64_t)(count - 1) * step < n;
+}
 static int encode_ranges(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d_dst, uint64_t cap, int format, int level,
                          uint32_t count, hipStream_t st, zz_result* host_res)
 {
@@ -759,6 +861,13 @@ static int encode_ranges(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint8_t* d
     if (cap < (uint64_t)hl) { set_err("destination smaller than the container header"); return ZZ_E_NOSPACE; }
     const int cks_kind = cks_kind_for(format);
     const uint64_t step = (n + count - 1) / count;                        // zzflate.cpp:70
+    // divideInRanges (zzflate.cpp:67-78) puts boundary i at step * i and only the last one at n: with count near sqrt(n) or
+    // above, the trailing boundaries lie at or past n (the reference then reads past its input and joins
+    // a stream that does not inflate -- undefined behaviour, nothing to equal). Refused here, before anything is launched.
+    if (!ranges_split_ok(n, count)) {
+        set_err("ranges: count too large for this input: (count - 1) * ceil(n / count) must be < n (zzflate.cpp:67-78 would cut ranges past the input's end)");
+        return ZZ_E_ARG;
+    }
     c->have_time = false;
     c->have_last = false;
     HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(zz_result), st));
@@ -969,10 +1078,11 @@ static int peer_prepare(int dst, int src)
             const int a = dir ? src : dst, b = dir ? dst : src;
             int can = 0;
             ok = hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can != 0 && hipSetDevice(a) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
             if (ok) {
                 const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
-                if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();      // idempotent: clear the sticky error
-                else ok = e == hipSuccess;
+                if (e != hipSuccess) (void)hipGetLastError();    // whatever it was: the thread's last-error word must not leak into the next launch check
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;             // (idempotent)
             }
         }
         (void)hipSetDevice(prev);
@@ -1575,7 +1685,10 @@ static int encode_host(const uint8_t* src, uint64_t n, const zz_config* cfg, hos
     {
         const char* e = getenv("ZZFLATE_RANGES");                         // (read per call: tests switch it)
         const int count = e ? atoi(e) : 0;
-        if (count > 0 && n > 0 && level != 1 && level <= 3) {
+        // (only where the split's preconditions hold -- count <= 4096, n < 2 GiB, every range inside the input; otherwise the
+        // call is served in packet mode like any other: the environment switch must not turn working calls into errors)
+        if (count > 0 && count <= 4096 && n > 0 && n < (1ull << 31) && level != 1 && level <= 3 &&
+            (n < 100ull * (uint64_t)count || ranges_split_ok(n, (uint32_t)count))) {
             rc = lease.take(devs[0]);
             if (rc) return rc;
             return encode_host_ranges(lease.v[0], src, n, format, level, (uint32_t)count, sink);

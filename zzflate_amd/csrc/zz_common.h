@@ -37,7 +37,11 @@ struct zz_packet_params {
     unsigned long long* prof; // diagnostic builds (-DZZ_PROF) only: per-phase cycle sums; ignored otherwise
     uint32_t warm;            // level 1: bytes in front of a packet hashed into its table before the parse (0: cold, the reference)
     const uint8_t* tail;      // k_encode_l1p: 128 bytes, the shard's last min(n, 64) bytes followed by zeros (k_fill_tail)
+    uint32_t dbg_viol;        // tests: report the LDS-order check as failed (error bit 4) whatever it saw
 };
+// bits of *err
+#define ZZ_ERR_SLOT_OVERFLOW 1u
+#define ZZ_ERR_LDS_ORDER 4u   // a kernel saw a slot keep a LOWER lane's store of an instruction a higher lane took part in
 
 // ---- the sequential stream's output buffers (outputbitstream.h:171-201) ------------------------------------------
 // A single Encoder asks EnsureOutputLength(length) at every block start. With a caller-owned buffer the answer is the

@@ -859,8 +859,14 @@ __device__ __forceinline__ l1_pk l1_packet_of(const zz_packet_params& P, uint32_
 // loads requested before this trip's are used (the window comes from the Infinity Cache, ~2 us).
 // MASKFREE: a lane without a position stores to a spare slot instead of sitting out under a lane mask (every masked region is
 // three scalar instructions); level 2's kernel has no registers to spare for the address selects and keeps the masks.
+// `viol` (in/out, per lane): set where the LDS did NOT keep that order -- checked on the last store of every trip (one read-back
+// per 512 positions: the slot must hold a position at or above the lane's own; a sampled run-time monitor behind the per-device
+// probe, zz_api.hip lds_order_ok). The caller reports it (ZZ_ERR_LDS_ORDER) and the host refuses the stream.
+// Level 2's kernel has no register for `viol` to live in (96 VGPRs, the limit of its five wavefronts per SIMD: the check spilled
+// into the block loops), so it checks the same property of the same LDS on a canary instead: all 64 lanes store lane + 1 to
+// the spare slot, which must then read 64 (MASKFREE = false; once per packet, behind the last trip).
 template <uint32_t BIAS, bool MASKFREE>
-__device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, int32_t W, const uint8_t* end, int keyoff, uint32_t spare)
+__device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, int32_t W, const uint8_t* end, int keyoff, uint32_t spare, uint32_t& viol)
 {
     const int lane = lane_id();
     auto request = [&](int32_t g, uint32_t (&w4)[8]) {
@@ -880,6 +886,11 @@ __device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, in
             const uint32_t hh = calc_hash3(w4[u]);
             if (MASKFREE) T[pos < 0 ? hh : spare] = (uint16_t)(pos + 1 + (int32_t)BIAS);
             else if (pos < 0) T[hh] = (uint16_t)(pos + 1 + (int32_t)BIAS);
+            if (MASKFREE && u == 7) {
+                ZZ_WAVE_SYNC();
+                const uint32_t mine = (uint32_t)(uint16_t)(pos + 1 + (int32_t)BIAS);
+                if ((uint32_t)T[pos < 0 ? hh : spare] < mine && pos < 0) viol = 1u;
+            }
         }
     };
     if (MASKFREE) {
@@ -908,6 +919,10 @@ __device__ __forceinline__ void warm_prehash(uint16_t* T, const uint8_t* src, in
         request(g + 16 * ZZ_WAVE, wa);
         enter(g + 8 * ZZ_WAVE, wb);
     }
+    ZZ_WAVE_SYNC();
+    T[spare] = (uint16_t)(lane + 1);                     // the canary: 64 lanes, one address
+    ZZ_WAVE_SYNC();
+    viol = (uint32_t)T[spare] != (uint32_t)ZZ_WAVE ? 1u : 0u;
 }
 
 template <uint32_t BIAS>
@@ -925,7 +940,9 @@ __device__ __forceinline__ void l1_packet_parser(const zz_packet_params& P, uint
     if (BIAS) {
         const uint64_t before = P.halo + q.off;                       // input bytes of this stream in front of the packet
         // key of a position: bytes pos+1..pos+3 (encoder.cpp:344); spare slot: the last half word of the hand-over slots, unused so far
-        warm_prehash<BIAS, true>(T, q.src, (int32_t)(before < P.warm ? before : P.warm), q.end, 1, (uint32_t)(((uint16_t*)tokbuf + 255) - T));
+        uint32_t viol = 0;
+        warm_prehash<BIAS, true>(T, q.src, (int32_t)(before < P.warm ? before : P.warm), q.end, 1, (uint32_t)(((uint16_t*)tokbuf + 255) - T), viol);
+        if ((ballot(viol != 0) != 0 || P.dbg_viol) && lane == 0) atomicOr(P.err, ZZ_ERR_LDS_ORDER);
     }
     bitring none;
     none.ring = nullptr; none.out32 = nullptr; none.bitpos = 0; none.flushed = 0;

@@ -84,6 +84,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
         l1p_ld128<true>(SRC, p0 < n ? p0 : n - 1, w, w2);
     }
     ZZ_PROF_DECL
+    // The invariant this kernel stands on, checked as it runs: where lanes of one block share a hash, the slot must end up with
+    // the HIGHEST of their positions (the read-back `rb` is at or above every such lane's own entry). viol = the largest
+    // rb - (p + 1) seen, unsigned: a lower lane's entry in the slot wraps it around. Two VALU instructions per block on the
+    // prober's side; reported at the packet's end (ZZ_ERR_LDS_ORDER), and the host runs the call again on k_encode_l1.
+    uint32_t viol = 0;
     uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
     uint32_t xlo_next = pw ? 1u : 0xFFFF0000u;                            // block 1: base - 63 = 1; block 0: nothing can be a cross lane
@@ -172,6 +177,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             if (lostmask) {
                 uint32_t W = (uint32_t)lane;
                 if (active) W = (rb - 1u - base) & 63u;
+                {
+                    const uint32_t d = rb - (p + 1u);                      // 0..63 where the order holds
+                    if (INT) viol = d > viol ? d : viol;
+                    else if (active && d > viol) viol = d;
+                }
                 myset = wave_match6(W);
                 const uint64_t below = myset & below_me;
                 const bool dup = below != 0 && active;
@@ -389,6 +399,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     }
     if (((NB - 1) & 1u) != pw) l1_group_barrier();                       // the other wavefront's last walk
     l1_group_barrier();                                                  // hand-over of the last block's tokens
+    if ((ballot(viol >= ZZ_WAVE) != 0 || P.dbg_viol) && lane == 0) atomicOr(P.err, ZZ_ERR_LDS_ORDER);
     ZZ_PROF_FLUSH(P);
 }
 
@@ -451,7 +462,7 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
     const uint32_t bytes = ring_finish(ring);
     if (lane == 0) {
         P.sizes[k] = bytes;
-        if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+        if (bytes > P.slot_stride) atomicOr(P.err, ZZ_ERR_SLOT_OVERFLOW);
     }
 }
 

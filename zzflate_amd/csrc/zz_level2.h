@@ -1123,7 +1123,9 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
                     // own three bytes (CalcHash(source + j), :388), ascending, per hash the highest stays
-                    warm_prehash<BIAS, false>(T, src, (int32_t)(before < P.warm ? before : P.warm), end, 0, (uint32_t)(ZZ_L2_LDS_BYTES / 2));
+                    uint32_t viol = 0;
+                    warm_prehash<BIAS, false>(T, src, (int32_t)(before < P.warm ? before : P.warm), end, 0, (uint32_t)(ZZ_L2_LDS_BYTES / 2), viol);
+                    if (viol | P.dbg_viol) atomicOr(P.err, ZZ_ERR_LDS_ORDER);     // (per lane, no ballot: this kernel has no scalar register to spare)
                 }
                 // 16-byte loads (own bytes, next block's prefetch) may run up to 15 bytes past the packet's last byte:
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
