@@ -660,7 +660,9 @@ def main():
         issue = None
         # which level-1 kernel ran: asked of the library (ZZFLATE_L1_KERNEL=classic and a negative LDS-order verdict both give k_encode_l1)
         l1_two = args.level == 1 and not args.warm and (not hasattr(zz.lib, "zz_debug_l1_kernel") or zz.lib.zz_debug_l1_kernel(ctx._h) == 2)
-        l1_kernel = "k_encode_l1w" if args.warm else ("k_encode_l1p" if l1_two else "k_encode_l1")
+        classic = os.environ.get("ZZFLATE_L1_KERNEL") == "classic"
+        l1_kernel = ("k_encode_l1w" if classic else "k_encode_l1pw") if args.warm else ("k_encode_l1p" if l1_two else "k_encode_l1")
+        l1_two = l1_two or (args.level == 1 and bool(args.warm) and not classic)
         scal = tj_scalar if (args.level == 1 and l1_two) or args.level in (2, 3) else None
         if insts and kms > 0 and args.level >= 1:
             resident = 256 * (8 if args.level >= 4 else 9) * (3 if l1_two else 2)     # k_encode_l1p: two parsers + the emitter per packet

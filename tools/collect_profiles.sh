@@ -22,7 +22,7 @@ run sq_l1     --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_
 # count quad-cycles: MI355X_MICROARCH.md); two passes of <= 8 SQ counters; a name this ROCm does not know fails that pass only
 run busy1_l1  --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES SQ_WAVES \
               --output-format csv -d "$OUT/busy1_l1" -- $B --steps 2 --warmup 1 --no-extra || echo "[collect] busy1_l1 failed (counter names?)"
-run busy2_l1  --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE \
+run busy2_l1  --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE \
               --output-format csv -d "$OUT/busy2_l1" -- $B --steps 2 --warmup 1 --no-extra || echo "[collect] busy2_l1 failed (counter names?)"
 run stats_l0  --kernel-trace --stats --output-format csv -d "$OUT/stats_l0" -- $B --steps 5 --warmup 1 --level 0 --gen random --no-extra
 run fetch_l0  --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_l0" -- $B --steps 2 --warmup 1 --level 0 --gen random --no-extra

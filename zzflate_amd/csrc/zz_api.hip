@@ -174,9 +174,9 @@ extern "C" int zz_ctx_create(int device, zz_ctx** out)
         HIPCHK(hipMalloc(&c->d_cks_total, sizeof(zz_cks_total)));
         HIPCHK(hipMalloc(&c->d_err, 4 * sizeof(uint32_t)));          // [0] slot overflow, [1] stream truncated, [2] log entries
         HIPCHK(hipMalloc(&c->d_work, 16 * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&c->d_prof, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&c->d_prof, 64 * sizeof(unsigned long long)));
         HIPCHK(hipMalloc(&c->d_tail, 128));
-        HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->d_prof, 0, 64 * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void**)&c->h_res, sizeof(zz_result), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&c->h_err, 4 * sizeof(uint32_t), hipHostMallocDefault));
         HIPCHK(hipEventCreate(&c->ev0));
@@ -406,6 +406,14 @@ extern "C" int zz_debug_read_prof(zz_ctx* c, unsigned long long out[16])
     HIPCHK(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
     return ZZ_OK;
 }
+// the same for kernels that keep one set of 16 counters per wavefront of the workgroup (k_encode_l1p: set w = wavefront w)
+extern "C" int zz_debug_read_prof_sets(zz_ctx* c, unsigned long long out[64])
+{
+    if (!c) return ZZ_E_ARG;
+    HIPCHK(hipMemcpy(out, c->d_prof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(c->d_prof, 0, 64 * sizeof(unsigned long long)));
+    return ZZ_OK;
+}
 // warm window. At level 1 the last `bytes` bytes (at most 32768) in front of every packet -- as far as
 // they exist in the stream: a shard must pass them as its halo -- are hashed into the packet's table before it is parsed,
 // so that matches may reach back across the packet boundary. 0 (the default) gives the reference's threaded stream.
@@ -568,7 +576,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);      // (what reads past the shard's end reads this)
             // ZZFLATE_L1_PAD_LDS (diagnostic): extra dynamic LDS per workgroup, to measure throughput vs. resident waves
             static const unsigned pad_lds = [] { const char* e = getenv("ZZFLATE_L1_PAD_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-            if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
+            // (a warm window exists only where the LDS-order verdict is positive: zz_ctx_set_warm_window; k_encode_l1w = the one-parser form, A/B)
+            if (pp.warm && !l1_classic()) hipLaunchKernelGGL(k_encode_l1pw, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
+            else if (pp.warm) hipLaunchKernelGGL(k_encode_l1w, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
             else if (!l1p) hipLaunchKernelGGL(k_encode_l1, dim3(npk), dim3(ZZ_L1_THREADS), pad_lds, st, pp);
             else hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
         } else {

@@ -91,10 +91,13 @@ __device__ __forceinline__ void zz_log_ensure(const zz_stream_ctl& C, uint32_t& 
 #define ZZ_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define ZZ_C(i, v) do { prof_acc[i] += (v); } while (0)
 #define ZZ_PROF_FLUSH(P) do { if (threadIdx.x == 0 && (P).prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&(P).prof[_i], prof_acc[_i]); } while (0)
+// one set of counters per wavefront of the workgroup (zz_debug_read_prof_sets)
+#define ZZ_PROF_FLUSH_W(P, w) do { if ((threadIdx.x & 63) == 0 && (P).prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&(P).prof[16 * (w) + _i], prof_acc[_i]); } while (0)
 #else
 #define ZZ_PROF_DECL
 #define ZZ_T(i)
 #define ZZ_DRAIN()
 #define ZZ_C(i, v)
 #define ZZ_PROF_FLUSH(P)
+#define ZZ_PROF_FLUSH_W(P, w)
 #endif

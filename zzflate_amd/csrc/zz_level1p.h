@@ -55,6 +55,10 @@ namespace zz {
 #ifndef ZZ_L1P_PRIO_E
 #define ZZ_L1P_PRIO_E 0         // ... and of the emitter
 #endif
+// the LDS-order invariant (l1p_parse, wmin): 1 = checked in every block (one VALU instruction), 0 = in a packet's last blocks only
+#ifndef ZZ_L1P_ORDER_CHECK
+#define ZZ_L1P_ORDER_CHECK 1
+#endif
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 #define ZZ_L1P_NONE 64u          // win[]: no lane of the block with that hash was visited
@@ -70,6 +74,12 @@ struct l1p_xch {
 
 // One parsing wavefront (pw = 0: even blocks, 1: odd blocks). Barriers: B_g closes the walk of block g - 1. Per block g its
 // owner runs  [P1 P2](g)  B_g  [R W](g)  B_g+1  [P4](g)  and then block g + 2; the other wavefront is one barrier out of step.
+//
+// BIAS = 32768 (k_encode_l1pw): the warm window (zz_level1.h, l1_packet_parser). Table entries are position + 1 +
+// BIAS, the positions -32768 .. -1 in front of the packet are in the table before block 0 is probed (warm_prehash), and an entry
+// further back than 32768 from the position that reads it is no candidate (encoder.cpp:348) -- decided by every READER for its own
+// position: the entry itself stays what it is (it is what `told` hands to the block behind and what the repair restores).
+template <uint32_t BIAS>
 __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk& pk, uint16_t* T, uint32_t* tokbuf, l1p_xch* X, const uint32_t pw)
 {
     const int lane = lane_id();
@@ -85,17 +95,18 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     }
     ZZ_PROF_DECL
     // The invariant this kernel stands on, checked as it runs: where lanes of one block share a hash, the slot must end up with
-    // the HIGHEST of their positions (the read-back `rb` is at or above every such lane's own entry). viol = the largest
-    // rb - (p + 1) seen, unsigned: a lower lane's entry in the slot wraps it around. Two VALU instructions per block on the
-    // prober's side; reported at the packet's end (ZZ_ERR_LDS_ORDER), and the host runs the call again on k_encode_l1.
-    uint32_t viol = 0;
+    // the HIGHEST of their positions, i.e. the lane the read-back names (rb - 1 - base, computed for the same-hash sets anyway)
+    // is never below the reading lane. wmin = the lowest such lane number this lane has seen over the packet's blocks: ONE
+    // v_min_u32 per block on the prober's side (in place: inline asm, no copy behind the uniform branch); reported at the packet's
+    // end where wmin < lane (ZZ_ERR_LDS_ORDER), and the host runs the call again on k_encode_l1 (zz_api.hip encode_finish).
+    uint32_t wmin = ZZ_WAVE;
     uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
-    uint32_t xlo_next = pw ? 1u : 0xFFFF0000u;                            // block 1: base - 63 = 1; block 0: nothing can be a cross lane
+    uint32_t xlo_next = pw ? 1u + BIAS : 0xFFFF0000u;                     // block 1: base - 63 = 1; block 0: nothing can be a cross lane
     for (uint32_t g = pw; g < NB; g += 2) {
         const uint32_t tag = (g + 1) << 16;                               // told[]'s tag: "these are block g's"
         const uint32_t xlo = xlo_next;
-        xlo_next = (g << 6) + (2 * ZZ_WAVE - (ZZ_WAVE - 1));              // block g + 2's: its base - 63
+        xlo_next = (g << 6) + (2 * ZZ_WAVE - (ZZ_WAVE - 1)) + BIAS;       // block g + 2's: its base - 63
         if (mycout >= 2 * ZZ_WAVE) {
             // A match found two blocks ago covers this block entirely (and the one between, which the other wavefront had probed by
             // then): nothing is probed, entered or walked -- the barriers, the carried match end and an empty token slot are all there
@@ -130,9 +141,10 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             // ---- P1: hash, probe + speculative insert (encoder.cpp:344-346); the candidate's bytes are requested at once
             const uint32_t h = calc_hash3((uint32_t)(w >> 8));
             const uint32_t oldraw = T[h];
-            T[h] = (uint16_t)(p + 1);
+            T[h] = (uint16_t)(p + 1 + BIAS);
             uint64_t wc, wc2;
-            l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(oldraw, 1u), wc, wc2);     // (no candidate: the packet's first bytes, unused)
+            if (BIAS == 0) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(oldraw, 1u), wc, wc2);     // (no candidate: the packet's first bytes, unused)
+            else l1p_ld128<!INT>(SRC, (p + 1 + BIAS - oldraw > 0x8000u) ? 0 : (int32_t)(oldraw - 1u - BIAS), wc, wc2);   // (none, or out of reach: likewise)
             uint64_t wn, wn2;                                            // this lane's bytes two blocks on: blocks are fixed, so the address is known
             if (!INT) { wn = 0; wn2 = 0; }
             if (INT || g + 2 < NB) {                                     // (an interior block has two whole blocks behind it: no test)
@@ -165,23 +177,27 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     v = *(volatile lds_u32*)&X->told[qa];
                 } while (ballot((v >> 16) != g) & XD);                   // (the scalar AND of two masks: no select, no second compare)
                 talt = v & 0xFFFFu;
-                if (xd) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(talt, 1u), wa, wa2);      // (a gather costs the address path per lane)
+                if (xd) {                                                // (a gather costs the address path per lane)
+                    if (BIAS == 0) l1p_ld128<!INT>(SRC, __builtin_elementwise_sub_sat(talt, 1u), wa, wa2);
+                    else l1p_ld128<!INT>(SRC, (p + 1 + BIAS - talt > 0x8000u) ? 0 : (int32_t)(talt - 1u - BIAS), wa, wa2);
+                }
             }
 
             // ---- P2: same-hash sets inside the block, lengths against every possible candidate (16 bytes compared)
-            const uint64_t lostmask = ballot(active && rb != (uint32_t)(uint16_t)(p + 1));
+            const uint64_t lostmask = ballot(active && rb != (uint32_t)(uint16_t)(p + 1 + BIAS));
             const uint32_t left = active ? n - p : 0;
             const uint32_t cap17 = INT ? 8u * (ZZ_WI_CAP + 1) : (left < ZZ_WI_CAP + 1 ? left : ZZ_WI_CAP + 1) << 3;
             uint64_t myset = self_bit;                  // the lanes of the block with my hash, myself included
             uint32_t infoB = 0;
+            // (the slot was written by lanes of THIS instruction with my hash, me among them, and reads back one of them: wraw is a lane
+            // number, 0..63, whatever order the LDS kept -- and wave_match6 looks at six bits only: no mask. The order check takes the
+            // instruction slot the mask had; in front of the branch, so that wmin is updated in place, no copy behind a merge.)
+            const uint32_t wraw = rb - 1u - BIAS - base;               // the lane whose store the slot kept
+            if (INT && ZZ_L1P_ORDER_CHECK) wmin = wraw < wmin ? wraw : wmin;
             if (lostmask) {
-                uint32_t W = (uint32_t)lane;
-                if (active) W = (rb - 1u - base) & 63u;
-                {
-                    const uint32_t d = rb - (p + 1u);                      // 0..63 where the order holds
-                    if (INT) viol = d > viol ? d : viol;
-                    else if (active && d > viol) viol = d;
-                }
+                uint32_t W = wraw;
+                if (!INT && !active) W = (uint32_t)lane;
+                if (!INT && active && wraw < wmin) wmin = wraw;
                 myset = wave_match6(W);
                 const uint64_t below = myset & below_me;
                 const bool dup = below != 0 && active;
@@ -223,9 +239,10 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 const uint32_t r = X->win[qa];
                 const bool moved = r != qa;
                 const bool use3 = r == ZZ_L1P_NONE;
-                const uint32_t toldh = (base - ZZ_WAVE + 1u) + r;
+                const uint32_t toldh = (base - ZZ_WAVE + 1u + BIAS) + r;
                 const uint32_t t1 = use3 ? talt : toldh;
                 told = moved ? t1 : oldraw;
+                ZZ_T(7);                                                   // (diagnostic builds: the two LDS reads have come back)
                 // the block behind is waiting for this (its cross lanes' second candidate): out first
                 X->told[lane] = told | tag;
                 const uint64_t LDM = ballot(moved) & ~ballot(use3);
@@ -236,7 +253,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     const uint64_t c = use3 ? wa : wc, c2 = use3 ? wa2 : wc2;
                     x = w ^ c;
                     uint32_t la = equal_bits128(x, w2 ^ c2, INT ? CAPA : cap17) >> 3;
-                    if (!told) la = 0;
+                    if (BIAS == 0 ? !told : (p + 1 + BIAS - told > 0x8000u)) la = 0;      // none (0: further back than anything), or out of reach
                     info = infoB | (INT ? la : (la > ZZ_WI_CAP ? (ZZ_WI_CAP | ZZ_WI_EXTA) : la));
                 };
                 // (ONE test of LDM, with the comparison in both arms: the test is scalar code on the critical path)
@@ -248,7 +265,8 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     // before anything else so that the comparison runs under the load (every lane loads: no lane mask to set
                     // up; the others read their own candidate's line again) -- 0.2 times per block of text, 0.35 of the mix
                     uint64_t l0, l1;
-                    l1p_ld128u<!INT>(SRC, __builtin_elementwise_sub_sat(told, 1u), l0, l1);
+                    if (BIAS == 0) l1p_ld128u<!INT>(SRC, __builtin_elementwise_sub_sat(told, 1u), l0, l1);
+                    else l1p_ld128<!INT>(SRC, (p + 1 + BIAS - told > 0x8000u) ? 0 : (int32_t)(told - 1u - BIAS), l0, l1);
                     compare();
                     const uint64_t x3 = w ^ l0;
                     const uint32_t la3 = equal_bits128(x3, w2 ^ l1, INT ? CAPA : cap17) >> 3;
@@ -258,6 +276,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 }
                 cin = uniform(sc);
             }
+            ZZ_T(8);                                                       // (the comparison)
             const uint64_t E = ballot((info & (ZZ_WI_HARD | 0x1Cu | (0x1Cu << ZZ_WI_LENB_SHIFT))) != 0);
             {
                 const uint32_t endl = (uint32_t)lane + (info & 31u);
@@ -271,7 +290,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint64_t mst = 0, usedB = 0;
             uint64_t cov;                                                // the lanes the match carried in covers: cin ones (all of them from 64 on)
             l1_walk_x Xw;
-            Xw.hash = h; Xw.wlo = (uint32_t)w; Xw.whi = (uint32_t)(w >> 32); Xw.candbase = base + 1; Xw.hardok = INT ? 1u : 0u;
+            Xw.hash = h; Xw.wlo = (uint32_t)w; Xw.whi = (uint32_t)(w >> 32); Xw.candbase = base + 1 + BIAS; Xw.hardok = INT ? 1u : 0u;
             // (the overrides' lanes are named by ovmL / ovmC; what the other lanes hold is never looked at: no zeroing)
             asm volatile("" : "=v"(Xw.ovlen), "=v"(Xw.ovcand1));
             Xw.ovmL = 0; Xw.ovmC = 0;
@@ -298,8 +317,8 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     mlen = useB ? ZZ_WI_LENB(inf) : ZZ_WI_LENA(inf);
                     if (mlen >= 4) {
                         if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
-                            const uint32_t cand = useB ? base + ZZ_WI_QLANE(inf) : readlane(told, e) - 1;
-                            mlen = l1p_extend_match(SRC, pe, (int32_t)cand, maxlen, ZZ_WI_CAP);
+                            const int32_t cand = useB ? (int32_t)(base + ZZ_WI_QLANE(inf)) : (int32_t)(readlane(told, e) - 1u - BIAS);
+                            mlen = l1p_extend_match(SRC, pe, cand, maxlen, ZZ_WI_CAP);
                             if (lane == e) ovlen = mlen | 0x8000u;
                             ovmL |= 1ull << e;
                         }
@@ -312,10 +331,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     uint64_t xe = ~0ull;
                     if (S) {
                         const int c = 63 - __builtin_clzll(S);
-                        cand1 = base + (uint32_t)c + 1;
+                        cand1 = base + (uint32_t)c + 1 + BIAS;
                         xe = readlane64(w, e) ^ readlane64(w, c);
                     } else {
                         cand1 = readlane(told, e);
+                        if (BIAS && pe + 1 + BIAS - cand1 > 0x8000u) cand1 = 0;      // out of reach (encoder.cpp:348)
                         if (cand1) {
                             xe = readlane64(x, e);
                         }
@@ -323,7 +343,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     mlen = 0;
                     if ((uint32_t)xe == 0 && maxlen >= 4) {
                         if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
-                        else mlen = l1p_extend_match(SRC, pe, (int32_t)(cand1 - 1), maxlen);
+                        else mlen = l1p_extend_match(SRC, pe, (int32_t)(cand1 - 1u - BIAS), maxlen);
                         if (mlen > maxlen) mlen = maxlen;
                     }
                     if (lane == e) { ovlen = mlen | 0x8000u; ovcand1 = cand1; }
@@ -370,12 +390,12 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             {
                 const uint32_t la_ = ZZ_WI_LENA(info) | 0x8000u, lb_ = ZZ_WI_LENB(info) | 0x8000u;     // ZZ_TOK_MATCH >> 16 rides along
                 const uint32_t tl = sel_lanes(ovmL, ovlen, sel_lanes(usedB, lb_, la_));
-                const uint32_t cn = sel_lanes(ovmC, ovcand1, sel_lanes(usedB, base + ZZ_WI_QLANE(info) + 1, told));
-                const uint32_t tmatch = (tl << 16) | (p + 1 - cn);
+                const uint32_t cn = sel_lanes(ovmC, ovcand1, sel_lanes(usedB, base + ZZ_WI_QLANE(info) + 1 + BIAS, told));
+                const uint32_t tmatch = (tl << 16) | (p + 1 + BIAS - cn);
                 const uint32_t tlit = ZZ_TOK_LIT | (uint32_t)(w & 0xFF);
                 *slot = keep_lanes(committed, sel_lanes(mst, tmatch, tlit));
             }
-            const uint64_t INB = ballot((rb2 - (base + 1)) < ZZ_WAVE);
+            const uint64_t INB = ballot((rb2 - (base + 1 + BIAS)) < ZZ_WAVE);
             const uint32_t taddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)(T + h);
             {
                 const uint64_t rm = INB & ~committed;                    // skipped lanes restore the old entry
@@ -388,7 +408,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 const uint64_t wm = ballot((myset & committed & above_me) == 0) & committed & INB;
                 uint64_t saved;
                 asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
-                             : "=&s"(saved) : "s"(wm), "v"(taddr), "v"(p + 1) : "memory", "scc");
+                             : "=&s"(saved) : "s"(wm), "v"(taddr), "v"(p + 1 + BIAS) : "memory", "scc");
             }
             ZZ_WAVE_SYNC();
             w = wn;
@@ -399,10 +419,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     }
     if (((NB - 1) & 1u) != pw) l1_group_barrier();                       // the other wavefront's last walk
     l1_group_barrier();                                                  // hand-over of the last block's tokens
-    if ((ballot(viol >= ZZ_WAVE) != 0 || P.dbg_viol) && lane == 0) atomicOr(P.err, ZZ_ERR_LDS_ORDER);
-    ZZ_PROF_FLUSH(P);
+    if ((ballot(wmin < (uint32_t)lane) != 0 || P.dbg_viol) && lane == 0) atomicOr(P.err, ZZ_ERR_LDS_ORDER);
+    ZZ_PROF_FLUSH_W(P, pw);
 }
 
+template <uint32_t BIAS>
 __device__ __forceinline__ void l1p_packet_parser(const zz_packet_params& P, uint32_t k, uint16_t* T, uint32_t* tokbuf, l1p_xch* X, uint32_t pw)
 {
     const int lane = lane_id();
@@ -414,12 +435,26 @@ __device__ __forceinline__ void l1p_packet_parser(const zz_packet_params& P, uin
     if (pw == 0) X->scal[lane] = 0;                                      // block 0: nothing carried in
     if (pw == 0) X->told[lane] = 0;                                      // (tag 0: no block's)
     if (pw == 1 && lane == 0) X->win[ZZ_L1P_SELF] = (uint8_t)ZZ_L1P_SELF; // the sentinel (zz_level1p.h, R)
+    if (BIAS) {
+        // the warm window: the first parser enters the last P.warm bytes in front of the packet (zz_level1.h warm_prehash: ascending,
+        // the LDS's own order leaves the highest position per hash -- checked as it goes) between two barriers, while the emitter
+        // sums the packet's Adler-32; the second parser's half of the table must be clear before the first entry lands
+        l1_group_barrier();                                              // B_c: the table is clear
+        if (pw == 0) {
+            const uint64_t before = P.halo + q.off;                      // input bytes of this stream in front of the packet
+            uint32_t viol = 0;
+            // key of a position: bytes pos+1..pos+3 (encoder.cpp:344); spare slot: the last half word of the hand-over slots, unused so far
+            warm_prehash<BIAS, true>(T, q.src, (int32_t)(before < P.warm ? before : P.warm), q.end, 1, (uint32_t)(((uint16_t*)tokbuf + 255) - T), viol);
+            if ((ballot(viol != 0) != 0 || P.dbg_viol) && lane == 0) atomicOr(P.err, ZZ_ERR_LDS_ORDER);
+        }
+    }
     l1_group_barrier();                                                  // B_z
     if (q.n > 0) {
-        l1p_parse(P, q, T, tokbuf, X, pw);
+        l1p_parse<BIAS>(P, q, T, tokbuf, X, pw);
     }
 }
 
+template <uint32_t BIAS>
 __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, uint32_t k, uint32_t* ring_words, const uint32_t* tokbuf)
 {
     const int lane = lane_id();
@@ -427,19 +462,24 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
     bitring ring;
     if (ZZ_L1P_PRIO_E) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_E);
     ring_init(ring, ring_words, q.out);
-    l1_group_barrier();                                                  // B_z
-    if (P.cks_kind == ZZ_CKS_ADLER) {                                    // while the parsers work on their first blocks
+    if (BIAS) l1_group_barrier();                                        // B_c
+    else l1_group_barrier();                                             // B_z
+    if (P.cks_kind == ZZ_CKS_ADLER) {                                    // while the parsers work on their first blocks (BIAS: on the window)
         zz_cks c = wave_adler(q.src, q.len);
         if (lane == 0) P.cks[k] = c;
     }
+    if (BIAS) l1_group_barrier();                                        // B_z
     if (q.n > 0) {
         ring_append_uniform(ring, (q.is_final ? 1u : 0u) | (1u << 1), 3);           // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
         const uint32_t NB = (q.n + ZZ_WAVE - 1) >> 6;
         const lds_u32* slot = (const lds_u32*)tokbuf + lane;
         l1_group_barrier();                                              // B_0
         l1_group_barrier();                                              // B_1
+        ZZ_PROF_DECL
         for (uint32_t g = 0; g < NB; ++g) {
+            ZZ_T(1); ZZ_C(10, 1);                                        // (diagnostic builds: [1] = emitting, [0] = asleep in the barrier)
             l1_group_barrier();                                          // B_g+2: block g's tokens are in slot g & 1
+            ZZ_T(0);
             const uint32_t tok = *slot;
             slot = lds_flip_slot((lds_u32*)slot);
 #ifdef ZZ_L1P_X_NOEMIT
@@ -448,6 +488,7 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
             l1_emit_tokens(ring, nullptr, tok);
         }
         ring_append_uniform(ring, 0, 7);                                 // EOB: codes_f[256] (encoder.cpp:371)
+        ZZ_PROF_FLUSH_W(P, 2);
     }
     if (!q.is_final) {
         // SetLevel(0); AddData(e-1, e): one stored byte = byte alignment (zzflate.cpp:118-120, encoder.cpp:482-502)
@@ -474,8 +515,20 @@ __global__ __launch_bounds__(ZZ_L1P_THREADS) void k_encode_l1p(zz_packet_params 
     __shared__ l1p_xch X;
     const uint32_t k = blockIdx.x;
     const uint32_t wv = uniform(threadIdx.x >> 6);
-    if (wv < 2) l1p_packet_parser(P, k, T, tokbuf, &X, wv);
-    else l1p_packet_emitter(P, k, ring_words, tokbuf);
+    if (wv < 2) l1p_packet_parser<0u>(P, k, T, tokbuf, &X, wv);
+    else l1p_packet_emitter<0u>(P, k, ring_words, tokbuf);
+}
+// the same with a warm window (P.warm > 0): table entries position + 1 + 32768, the window entered before block 0 is probed
+__global__ __launch_bounds__(ZZ_L1P_THREADS) void k_encode_l1pw(zz_packet_params P)
+{
+    __shared__ uint16_t T[ZZ_HASH_SIZE];
+    __shared__ uint32_t ring_words[ZZ_RING_WORDS];
+    __shared__ __attribute__((aligned(512))) uint32_t tokbuf[2 * ZZ_L1_TOKSLOT];
+    __shared__ l1p_xch X;
+    const uint32_t k = blockIdx.x;
+    const uint32_t wv = uniform(threadIdx.x >> 6);
+    if (wv < 2) l1p_packet_parser<32768u>(P, k, T, tokbuf, &X, wv);
+    else l1p_packet_emitter<32768u>(P, k, ring_words, tokbuf);
 }
 
 }  // namespace zz
