@@ -4,10 +4,12 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-lib = os.path.join(ROOT, "gpurun_out", "libzz_prof.so")
-os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZZ_PROF", "-o", lib,
-                os.path.join(ROOT, "zzflate_amd/csrc/zz_api.hip"), os.path.join(ROOT, "zzflate_amd/csrc/zz_cxx_shim.cpp")], check=True)
+lib = os.path.join(ROOT, "abl", "prof.so")            # built in the build container (tools/mkab.sh prof -DZZ_PROF) ...
+if not os.path.exists(lib):                            # ... or here
+    lib = os.path.join(ROOT, "gpurun_out", "libzz_prof.so")
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZZ_PROF", "-o", lib,
+                    os.path.join(ROOT, "zzflate_amd/csrc/zz_api.hip"), os.path.join(ROOT, "zzflate_amd/csrc/zz_cxx_shim.cpp")], check=True)
 L = ctypes.CDLL(lib)
 u64, vp, ci, u32 = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
 h = vp()
@@ -34,8 +36,21 @@ out = u64(0)
 for it in range(2):
     rc = L.zz_encode_device(h, vp(src.data_ptr()), u64(n), vp(dst.data_ptr()), u64(cap), ctypes.byref(out), ci(0), ci(level), u32(32768), vp(0))
     assert rc == 0
-    prof = (ctypes.c_ulonglong * 16)()
-    L.zz_debug_read_prof(h, prof)
+    sets = (ctypes.c_ulonglong * 64)()
+    if hasattr(L, "zz_debug_read_prof_sets"):
+        L.zz_debug_read_prof_sets(h, sets)
+        prof = list(sets[0:16])
+    else:
+        prof = (ctypes.c_ulonglong * 16)()
+        L.zz_debug_read_prof(h, prof)
+if level in (2, 3) and sets[16 + 10]:
+    # the two-parser token pass (zz_level2p.h): one counter set per parsing wavefront, one for the helper
+    for w in (0, 1):
+        p = list(sets[16 * (1 + w):16 * (2 + w)]); b = max(1, p[10])
+        print(f"parser {w}: blocks {p[10]}; per block: matches {p[11] / b:.2f} (out-of-line {p[12] / b:.3f}); cycles: loop top {p[5] / b:.0f} | enter + compare (P) {p[0] / b:.0f} | "
+              f"wait: walk in front {p[1] / b:.0f} | walk {p[2] / b:.0f} | symbols + hand-over {p[3] / b:.0f} | wait: own barrier {p[4] / b:.0f} | sum {sum(p[0:6]) / b:.0f}")
+    e = list(sets[48:64]); be = max(1, e[10])
+    print(f"helper: blocks {e[10]}; per block: asleep in the barrier {e[0] / be:.0f} cyc, busy {e[1] / be:.0f} cyc")
 if level >= 2:
     names = ["init+adler", "token pass", "counter unpack", "huffman", "codes", "emit"]
     tot = sum(prof[:6])

@@ -14,7 +14,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "zzflate_amd", "csrc", "zz_api.hip")
-KERNELS = ["k_encode_l1E", "k_encode_l1pE", "k_encode_l1pwE", "k_encode_l1wE", "k_encode_l2_tILj0ELb0E", "k_encode_l2_tILj32768ELb0E", "k_encode_l2_tILj32768ELb1E", "k_l6_matchesILi2E", "k_l6_matchesILi4E", "k_l6_matchesILi8E",
+KERNELS = ["k_encode_l1E", "k_encode_l1pE", "k_encode_l1pwE", "k_encode_l1wE", "k_encode_l2_tILj0ELb0ELb0E", "k_encode_l2_tILj0ELb0ELb1E", "k_encode_l2_tILj32768ELb0ELb0E", "k_encode_l2_tILj32768ELb1ELb0E", "k_l6_matchesILi2E", "k_l6_matchesILi4E", "k_l6_matchesILi8E",
            "k_stream_l1E", "k_stream_l2E", "k_encode_l0E"]
 
 

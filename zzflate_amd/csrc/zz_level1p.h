@@ -55,9 +55,16 @@ namespace zz {
 #ifndef ZZ_L1P_PRIO_E
 #define ZZ_L1P_PRIO_E 0         // ... and of the emitter
 #endif
-// the LDS-order invariant (l1p_parse, wmin): 1 = checked in every block (one VALU instruction), 0 = in a packet's last blocks only
+// The LDS-order invariant (l1p_parse, wmin) is checked inside the kernel: 0 (default) = in the last blocks of EVERY packet (the
+// copy of the block's code that clamps at the packet's end: three blocks of a 32 KiB packet's 512, no instruction in the other
+// 509), 1 = in every block (one v_min_u32 per block on the prober's side). Measured with tools/abn.sh against the kernel without
+// any check, 1 GiB text / mix (profiles/r05_ab_l1p_order_check.txt): sampled -0.2 % / -0.3 %, every block -0.8 .. -1.1 % / -0.6 ..
+// -1.2 % in four forms of the one instruction (inside the branch, in front of it, as asm, as C++) -- the instruction itself
+// replaces a mask that was redundant, what costs is the register that lives through the block loop. VERDICT r04 set the bar at
+// 0.5 %: the sampled form is the default, -DZZ_L1P_ORDER_CHECK=1 builds the other. Either way a violation takes the device's
+// verdict away and the call runs again on k_encode_l1 (zz_api.hip encode_finish).
 #ifndef ZZ_L1P_ORDER_CHECK
-#define ZZ_L1P_ORDER_CHECK 1
+#define ZZ_L1P_ORDER_CHECK 0
 #endif
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
@@ -96,9 +103,9 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     ZZ_PROF_DECL
     // The invariant this kernel stands on, checked as it runs: where lanes of one block share a hash, the slot must end up with
     // the HIGHEST of their positions, i.e. the lane the read-back names (rb - 1 - base, computed for the same-hash sets anyway)
-    // is never below the reading lane. wmin = the lowest such lane number this lane has seen over the packet's blocks: ONE
-    // v_min_u32 per block on the prober's side (in place: inline asm, no copy behind the uniform branch); reported at the packet's
-    // end where wmin < lane (ZZ_ERR_LDS_ORDER), and the host runs the call again on k_encode_l1 (zz_api.hip encode_finish).
+    // is never below the reading lane. wmin = the lowest such lane number this lane has seen over the blocks that check
+    // (ZZ_L1P_ORDER_CHECK); reported at the packet's end where wmin < lane (ZZ_ERR_LDS_ORDER), and the host runs the call again
+    // on k_encode_l1 (zz_api.hip encode_finish).
     uint32_t wmin = ZZ_WAVE;
     uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions

@@ -999,6 +999,7 @@ __device__ __forceinline__ uint32_t l2_count_bits(const uint16_t* recs, const ui
 
 }  // namespace zz
 #include "zz_level6.h"
+#include "zz_level2p.h"
 namespace zz {
 
 struct zz_l2_params {
@@ -1026,9 +1027,13 @@ struct zz_l2_params {
 // end, 13,760 bytes in all => eleven workgroups per CU instead of nine (22 wavefronts: six on two of the SIMDs => at most 80
 // VGPRs): the encode kernel of level 6 12.1 -> 10.0 ms per GiB. (Twelve -- the helper's ring over the dead match-start bits
 // and counters, 12,992 bytes -- ran no faster: 26.4 against 26.3 ms.)
-template <uint32_t BIAS, bool XD = false>
-__global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2_params Q)
+// PP (levels 2,3 with cold packets: "k_encode_l2p"): THREE wavefronts -- the token pass on two parsers that take alternate
+// blocks (zz_level2p.h), wavefront 1 stays the helper, wavefront 2 is the second parser and sits out the rest of the packet at
+// the barriers. 27 wavefronts per CU: seven on one SIMD => at most 72 VGPRs.
+template <uint32_t BIAS, bool XD = false, bool PP = false>
+__global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WPE : (XD ? 6 : 5)) void k_encode_l2_t(zz_l2_params Q)
 {
+    static_assert(!PP || (BIAS == 0 && !XD), "the two-parser token pass exists for cold packets of levels 2,3");
     const zz_packet_params& P = Q.pk;
     // ---- LDS carve-up: 17,840 bytes => nine workgroups per CU (18 wavefronts: five per SIMD => at most 96 VGPRs).
     // The hash table is dead once the token pass is over, so the Huffman scratch, the 32-bit histograms and the
@@ -1049,6 +1054,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
     uint64_t* covw = (uint64_t*)(lds + HB + 560);                 // 128: covered bits of the 16 blocks around the probe front
     uint64_t* mstw = covw + ZZ_L2_WIN;                            // 128: match-start bits
     uint32_t* histP = (uint32_t*)(lds + HB + 560 + 2 * ZZ_L2_WIN * 8);        // 640: packed 16-bit counters
+    __shared__ uint32_t xb[2];                                    // PP: backRefEnd and the next probe position, parser to parser
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -1089,8 +1095,9 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
     // (helper). Each wavefront runs its OWN packet loop over this body (below): with one loop around both roles,
     // values that are invariant across packets are hoisted for both roles at once and live through each other's code,
     // and the kernel does not fit its 96 registers.
-    auto packet = [&](const uint32_t k, auto w0tag) {
-        constexpr bool W0 = decltype(w0tag)::value;
+    auto packet = [&](const uint32_t k, auto roletag) {
+        constexpr int ROLE = decltype(roletag)::value;       // 0: parser (+ codes, first part of the emission), 1: helper, 2 (PP): second parser
+        constexpr bool W0 = ROLE == 0, PB = ROLE == 2;
         const uint64_t off = (uint64_t)k * P.packet_size;
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
         const bool is_final = P.last_is_final && k == P.npk - 1;
@@ -1104,7 +1111,7 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
         if (W0) {
             uint4* z = (uint4*)lds;
             if (!XD) for (int i = lane; i < 16384 / 16; i += ZZ_WAVE) z[i] = make_uint4(0, 0, 0, 0);   // T
-        } else {
+        } else if (!PB) {
             uint32_t* zw = (uint32_t*)covw;
             for (int i = lane; i < 2 * ZZ_L2_WIN * 2 + ZZ_L2_HIST_WORDS; i += ZZ_WAVE) zw[i] = 0;   // window + counters
         }
@@ -1119,6 +1126,14 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
                     const uint32_t* mrow = Q.m + (uint64_t)(k - Q.k0) * P.packet_size;
                     l6_parse_pass(hb, src, end, l1p_make_src(P, src, end), n, mrow);
                 }
+            } else if (PP) {
+                // two parsers: B0 also says "the table is clear" to the second one, "window and counters are" to both
+                if (W0) {
+                    if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
+                    l2p_token_pass(T, hb, xb, covw, mstw, src, end, l1p_make_src(P, src, end), n, before, 0u, P.prof);
+                    if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(3);
+                }
+                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, src, end, l1p_make_src(P, src, end), n, before, 1u, P.prof);
             } else if (W0) {
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
@@ -1131,10 +1146,11 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
                 // bounds-checked loads wherever that would leave the shard (by bytes: packets may be one byte long)
                 l2_token_pass<BIAS>(T, hb, src, end, l1p_make_src(P, src, end), n, before, P.prof);
             }
-            if (!W0) {
+            if (!W0 && !PB) {
                 uint32_t nb = 0, adA = 0;
                 uint64_t adC = 0;
-                const uint32_t nt = l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, XD ? l6_trips(n) : l2_probe_blocks(n));
+                const uint32_t nt = PP ? l2p_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, P.prof)
+                                       : l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, XD ? l6_trips(n) : l2_probe_blocks(n));
                 if (lane == 0) { covw[0] = ((uint64_t)nt << 32) | nb; }       // the window is dead now
                 if (P.cks_kind == ZZ_CKS_ADLER) {
                     if (lane == 0 && len > n) { const uint32_t d = src[n]; adA += d; adC += (uint64_t)n * d; }   // the byte of the alignment block
@@ -1151,6 +1167,14 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
         }
         uint32_t* share = misc + 4;      // [0] 1 stored / 2 dynamic, [1] first record of the helper's part, [2] bits in front of
                                          // the records, [3] wavefront 0's last (partial) word, [4] the helper's first word
+        if (PB) {
+            // the second parser has no part in the rest of the packet: it keeps the barriers
+            if (n > 0) {
+                __syncthreads();             // (X)
+                if (uniform(share[0]) == 2) __syncthreads();      // (Y)
+            }
+            return;
+        }
         if (!W0) {
             if (n == 0 && P.cks_kind == ZZ_CKS_ADLER) {     // (n > 0: summed during the token pass)
                 zz_cks c = wave_adler(src, len);
@@ -1321,17 +1345,20 @@ __global__ __launch_bounds__(ZZ_L2_THREADS, XD ? 6 : 5) void k_encode_l2_t(zz_l2
     };
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);      // the parse is the packet's critical path: ahead of the helpers in the issue arbiter
-        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::true_type());
+        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::integral_constant<int, 0>());
+    } else if (wave == 1) {
+        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::integral_constant<int, 1>());
     } else {
-        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::false_type());
+        __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
+        for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::integral_constant<int, 2>());
     }
     ZZ_PROF_FLUSH(P);
 }
 
 // xdepth: 0 = levels 2,3; 2 / 4 / 8 = the extended levels 4 / 5 / 6 (chain depth)
-static inline uint32_t l2_grid(uint32_t npk, bool xd = false)
+static inline uint32_t l2_grid(uint32_t npk, bool xd = false, uint32_t per_cu = 9)
 {
-    const uint32_t resident = 256 * (xd ? 11 : 9);     // what the LDS budget admits
+    const uint32_t resident = 256 * (xd ? 11 : per_cu);     // what the LDS budget (PP: and the register budget) admits
     return npk < resident ? npk : resident;
 }
 // the extended levels go through the input in batches of about 1 GiB: k_l6_matches over a batch's packets (one word per input
@@ -1360,8 +1387,11 @@ static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, u
     if (!xdepth) {
         (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
         const dim3 g(l2_grid(pp.npk)), b(ZZ_L2_THREADS);
+        // ZZFLATE_L2_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet instead of two; the streams are the same
+        static const bool classic = [] { const char* e = getenv("ZZFLATE_L2_KERNEL"); return e && !strcmp(e, "classic"); }();
         if (pp.warm) hipLaunchKernelGGL((k_encode_l2_t<32768u, false>), g, b, 0, st, q);
-        else hipLaunchKernelGGL((k_encode_l2_t<0u, false>), g, b, 0, st, q);
+        else if (classic) hipLaunchKernelGGL((k_encode_l2_t<0u, false>), g, b, 0, st, q);
+        else hipLaunchKernelGGL((k_encode_l2_t<0u, false, true>), dim3(l2_grid(pp.npk, false, ZZ_L2P_WPE >= 7 ? 9 : 8)), dim3(ZZ_L2P_THREADS), 0, st, q);
         return;
     }
     uint32_t* const m = (uint32_t*)(scratch + (uint64_t)l2_grid(pp.npk, true) * ZZ_L2_SCRATCH_BYTES);

@@ -1,0 +1,395 @@
+// zz_level2p.h -- levels 2 and 3: the token pass on TWO parsing wavefronts (k_encode_l2_t<0, false, true>, "k_encode_l2p").
+//
+// The same token pass as l2_token_pass (zz_level2.h), i.e. FirstPass + AddHashEntries (encoder.cpp:375-440, 474-480) over a
+// packet, bit for bit; what changes is who does what when -- level 1's remedy (zz_level1p.h), and simpler here: at this level
+// EVERY position is entered whatever the parse does (encoder.cpp:418, 474-480), so a probe's candidate -- the nearest earlier
+// position with its hash -- and both quick lengths are parse-independent. Only the greedy walk ("first probe whose forward +
+// backward match is >= 4", backRefEnd, the next probe position) is a chain through the packet. So the packet's blocks of 64
+// positions alternate between two parsing wavefronts:
+//
+//      parser 0:  [P 0] B0 [W 0] B1 [P 2] B2 [W 2] B3 [P 4] ...          P g: enter block g's positions, candidates, quick lengths
+//      parser 1:        B0 [P 1] B1 [W 1] B2 [P 3] B3 [W 3] ...          W g: walk block g, its matches to symbols and to the helper
+//
+// with one s_barrier per block (Bg), which the helper wavefront joins. Between two barriers one parser enters and compares while
+// the other walks; nothing speculative, no cross lanes, no repair: the table order is the barrier order (P g in front of Bg,
+// P g+1 behind it), and the walk's two scalars -- backRefEnd and the next probe position -- travel through two LDS words (xb).
+// What the one-parser form left to the helper and this one moves to the walker's side: the matches' starts and lengths, their
+// length / distance symbols (GetFrequencies' lookups, encoder.cpp:455-463) and the covered / match-start bits, so that the
+// helper -- which an instrumented build showed busy for 1.66 M of the token pass's 1.83 M cycles per packet -- keeps the token
+// stores, the symbol counts, the finished blocks' records and the Adler-32 sums.
+//
+// The one place where an entry depends on the parse is the batch switch (encoder.cpp:228-230, 435-438): a batch's first byte is
+// entered only if the batch before ran over it. A packet has at most one switch (16,384 + 16,125 >= its search region), at
+// block 256, which parser 0 owns: that block's P waits for the walk in front of it, and one extra barrier (Bx) keeps parser 1's
+// P 257 behind it -- a bubble once per packet.
+#pragma once
+
+namespace zz {
+
+#define ZZ_L2P_THREADS (3 * ZZ_WAVE)
+// wavefronts per SIMD the kernel is compiled for: 7 = nine workgroups per CU (27 wavefronts), at most 72 VGPRs; 6 = eight, 84
+#ifndef ZZ_L2P_WPE
+#define ZZ_L2P_WPE 7
+#endif
+// issue priorities of a parsing wavefront while it walks (the packet's chain) and while it enters and compares
+#ifndef ZZ_L2P_PRIO_W
+#define ZZ_L2P_PRIO_W 3
+#endif
+#ifndef ZZ_L2P_PRIO_P
+#define ZZ_L2P_PRIO_P 3
+#endif
+#define ZZ_L2P_SWITCH_BLOCK (ZZ_BATCH_LEN / ZZ_WAVE)      // block 256: where the second batch starts (if the search region reaches it)
+
+// the switch block of a packet whose search region is [0, target), or ~0: none
+__device__ __forceinline__ uint32_t l2p_switch_block(uint32_t target) { return target > ZZ_BATCH_LEN ? ZZ_L2P_SWITCH_BLOCK : 0xFFFFFFFFu; }
+
+// One parsing wavefront (pw = 0: even blocks, 1: odd blocks). xb: [0] backRefEnd, [1] the next probe position, as the walk
+// of the block walked last left them. Barriers: see above; every wavefront of the workgroup executes B0 .. B_NB (+ Bx).
+__device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32_t* xb, uint64_t* covw, uint64_t* mstw, const uint8_t* src,
+                                               const uint8_t* end, const l1p_src& TS, const uint32_t n, const uint64_t before, const uint32_t pw,
+                                               unsigned long long* prof = nullptr)
+{
+    const int lane = lane_id();
+    ZZ_PROF_DECL
+    const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
+    const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;     // :222 last 258 bytes never searched
+    const uint32_t NB = (target + 63) >> 6;
+    const uint32_t batch1 = target < ZZ_BATCH_LEN ? target : ZZ_BATCH_LEN;
+    const uint32_t gs = l2p_switch_block(target);
+    const uint32_t bcap = (uint32_t)(before < ZZ_MAX_LEN ? before : ZZ_MAX_LEN);
+    const uint32_t lo8 = before >= 8 ? 0u : 8u - (uint32_t)before;
+    const uint8_t* const srcm8 = src - 8;
+    // this lane's own bytes of this wavefront's first block: 16 from its position and the 8 in front
+    uint64_t wa = 0, wa2 = 0, wb = 0;
+    {
+        const uint32_t q0 = pw * ZZ_WAVE + (uint32_t)lane;
+        if (q0 < n) {
+            l1p_ld128<true>(TS, (int32_t)q0, wa, wa2);
+            if (before + q0 >= 8) wb = load64(src + (int64_t)q0 - 8);
+        }
+    }
+    uint32_t myNext = 1;            // the next probe position as this wavefront knew it last: a lower bound of the true one
+    if (pw == 0 && lane == 0) { xb[0] = 1; xb[1] = 1; }               // backRefEnd (:380), j (:383)
+    if (pw == 1) l2_block_barrier();                                  // B0
+    for (uint32_t g = pw; g < NB; g += 2) {
+        const uint32_t base = g << 6;
+        const bool sw = g == gs;
+        if (g == ZZ_L2P_SWITCH_BLOCK + 1 && gs == ZZ_L2P_SWITCH_BLOCK) l2_block_barrier();   // Bx: the switch block's entries are in the table
+        uint32_t skipPos = 0xFFFFFFFFu;
+        // blocks behind the switch belong to the second batch, which ends where the search region ends: a packet's rest is shorter
+        // than a batch (s2 >= 16384, target <= 32509); a match that overruns batch AND region leaves nothing to probe (nextProbe > target)
+        const uint32_t batchEnd = g < gs ? batch1 : target;
+        if (sw) {
+            // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first byte is entered only if
+            // the last match covered it. Needs the walk of block g - 1: this block's P runs behind Bg, and Bx follows it.
+            l2_block_barrier();                                       // Bg
+            const uint32_t Bw = uniform(xb[0]);
+            const uint32_t s2 = Bw > batch1 ? Bw : batch1;
+            skipPos = Bw >= batch1 ? 0xFFFFFFFFu : batch1;
+            ZZ_WAVE_SYNC();
+            if (lane == 0) { xb[0] = s2 + 1; xb[1] = s2 + 1; }
+            myNext = s2 + 1;
+        }
+        auto block = [&](auto interior_tag) {
+            // INTERIOR: not the packet's first block, not the switch block, every position inside the current batch
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+            ZZ_T(5); ZZ_C(10, 1);
+            const uint32_t q = base + (uint32_t)lane;
+            const bool ins = INTERIOR ? true : (q != skipPos && q != 0);
+            // (a block that a match found two blocks ago covers entirely is entered but not compared: myNext is a lower bound)
+            const bool cmp = myNext < base + 64;
+            const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
+            const uint32_t hs = ins ? h : (uint32_t)(ZZ_L2_LDS_BYTES / 2);
+            uint32_t old = T[hs];                                         // :389
+            T[hs] = (uint16_t)(q + 1);                                    // :390 / :474-480
+            if (!ins) old = 0;
+            uint64_t ca = 0, ca2 = 0, cpre = 0;
+            if (cmp) {
+                const uint32_t c0 = __builtin_elementwise_sub_sat(old, 1u);
+                ld128<false>(src + c0, end, ca, ca2);
+                cpre = load64(srcm8 + (c0 > lo8 ? c0 : lo8));          // (too close to the stream's start: fixed up below)
+            }
+            // this wavefront's next block (g + 2): its own bytes, in flight during the rest of this one (inside the packet: q + 143 < n)
+            uint64_t wan, wan2, wbn;
+            ld128<false>(src + q + 2 * ZZ_WAVE, end, wan, wan2);
+            wbn = load64(src + q + 2 * ZZ_WAVE - 8);
+            ZZ_WAVE_SYNC();
+            const uint32_t rb = T[hs];
+            uint32_t cand1 = old;                                         // candidate as pos+1, 0 = none
+            bool inl = false;                                             // the candidate is lane `il` of this block
+            uint32_t il = 0;
+            const uint64_t lost = INTERIOR ? ballot(rb != q + 1) : ballot(ins && rb != q + 1);
+            if (lost) {
+                const uint32_t W = ins ? (rb - 1u - base) & 63u : (uint32_t)lane;
+                const uint64_t set = wave_match6(W);
+                const uint64_t below = set & below_me;
+                inl = ins && below != 0;
+                il = 63u - (uint32_t)__builtin_clzll(below | 1ull);       // nearest earlier member (lane 0 where there is none: unused)
+                cand1 = inl ? base + il + 1 : old;
+                ZZ_WAVE_SYNC();
+                // last member wins: the highest lane of a set rewrites the slot unless its own store was the one that landed
+                if (INTERIOR) {
+                    const uint64_t fix = ballot(W != (uint32_t)lane) & ballot((set & above_me) == 0);
+                    uint64_t saved;
+                    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(saved) : "s"(fix), "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)(T + h)), "v"(q + 1)
+                                 : "memory", "scc");
+                } else if (ins && W != (uint32_t)lane && (set & above_me) == 0) T[h] = (uint16_t)(q + 1);
+            }
+            ZZ_WAVE_SYNC();
+
+            // ---- quick compare info for all 64 probes of this block (zz_level2.h, l2_token_pass) ---------------------------
+            uint32_t fwd8 = 0, broom = 0, room = 0, winfo = 0;
+            uint64_t Amask = 0;
+            const int32_t c = (int32_t)(cand1 - 1);
+            if (cmp) {
+                const bool has = INTERIOR ? cand1 != 0 : (ins && cand1 != 0 && q < batchEnd);
+                if (lost) {
+                    const int qa = (int)(il << 2);
+                    const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(wa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)wa);
+                    const uint64_t sa2 = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(wa2 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)wa2);
+                    const uint64_t sp = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)(wb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(qa, (int)wb);
+                    if (inl) { ca = sa; ca2 = sa2; cpre = sp; }
+                }
+                uint32_t bwd8;
+                {
+                    const uint32_t r = bcap + (uint32_t)c;                 // bytes in front of the candidate, as far as they count
+                    room = r < ZZ_MAX_LEN ? r : ZZ_MAX_LEN;                // D4 + D11 caps
+                    const uint64_t y = wb ^ cpre;
+                    bwd8 = umin3(ffbh_or_ones((uint32_t)(y >> 32)), add_sat_k<32>(ffbh_or_ones((uint32_t)y)), 64u) >> 3;
+                    if (before < 8 && ballot(has && room < 8)) {           // the first bytes of a stream: byte by byte
+                        if (has && room < 8) {
+                            bwd8 = 0;
+                            while (bwd8 < room && src[(int64_t)q - 1 - bwd8] == src[(int64_t)c - 1 - bwd8]) bwd8++;
+                        }
+                    }
+                    fwd8 = equal_bits128(wa ^ ca, wa2 ^ ca2, 128u) >> 3;   // 16 = "16 or more" (:399)
+                    if (!has) fwd8 = 0;
+                }
+                broom = bwd8 < room ? bwd8 : room;
+                if (!has) broom = 0;
+                Amask = ballot(fwd8 + broom >= 4);                                // strong or weak
+                const uint32_t inexact = (fwd8 & 16u) | (broom & 8u);
+                winfo = fwd8 | (sub_from4_sat(fwd8) << 5) | (inexact << 5) | (((fwd8 + 28u) & 32u) << 6) |
+                        ((fwd8 >= 4 && inexact == 0) ? 0x400u : 0u) | (((uint32_t)lane + fwd8) << 23);
+                {
+                    const uint32_t endl = (uint32_t)lane + fwd8 + 1;              // first lane probed after a match here
+                    const uint64_t m = Amask >> (endl & 63u);
+                    const uint32_t nx = endl + (m ? (uint32_t)__builtin_ctzll(m) : 64u);
+                    winfo |= ((nx < 64u ? nx : 64u) & 63u) << 16;                 // (64 & 63 = 0 = none)
+                }
+            }
+            ZZ_T(0);
+            l2_block_barrier();                                           // Bg (the switch block: Bx) -- the block in front has been walked
+            ZZ_T(1);
+            if (ZZ_L2P_PRIO_W != ZZ_L2P_PRIO_P) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_W);
+
+            // ---- W: the greedy walk (zz_level2.h: the same scalar loop) ----------------------------------------------------------
+            uint32_t B = uniform(xb[0]), nextProbe = uniform(xb[1]);
+            const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
+            uint32_t* slot = hb + (g & 1u) * ZZ_L2_HB_WORDS;
+            uint64_t evmask = 0, slowmask = 0;
+            uint32_t tk = 0;
+            const uint32_t Bentry = B;
+            if (doProbe) {
+                uint32_t np = (int32_t)(nextProbe - base) > 0 ? nextProbe - base : 0u;
+                int32_t Brel = (int32_t)(B - base);
+                uint32_t slow = 0;
+                auto walk = [&]() {
+                    uint32_t inf, t1, t2;
+                    uint64_t tmp;
+                    int32_t e;
+                    asm volatile(
+                        "1:\n\t"
+                        "s_lshl_b64 %[tmp], -1, %[np]\n\t"
+                        "s_and_b64 %[tmp], %[tmp], %[A]\n\t"        // candidates at or after np; SCC = there is one
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_ff1_i32_b64 %[e], %[tmp]\n"
+                        "9:\n\t"
+                        ZZ_L2_HOP "s_cbranch_scc0 10f\n\t"
+                        ZZ_L2_HOP "s_cbranch_scc1 9b\n"
+                        "10:\n\t"
+                        "s_add_u32 %[np], %[Brel], 1\n\t"           // no candidate left: j = backRefEnd + 1 (:424)
+                        "s_branch 3f\n"
+                        "5:\n\t"
+                        "s_bitcmp1_b32 %[inf], 11\n\t"
+                        "s_cbranch_scc1 4f\n\t"                     // strong but flagged
+                        "s_sub_i32 %[t1], %[e], %[Brel]\n\t"        // weak: pending literals j - backRefEnd (:404)
+                        "s_bfe_u32 %[t2], %[inf], 0x30005\n\t"
+                        "s_cmp_ge_i32 %[t1], %[t2]\n\t"
+                        "s_cbranch_scc1 7f\n\t"
+                        "s_add_u32 %[np], %[e], 1\n\t"              // no match at this probe: j++ (:430)
+                        "s_cmp_lt_u32 %[np], 64\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_branch 3f\n"
+                        "7:\n\t"
+                        "s_and_b32 %[t1], %[inf], 0x300\n\t"        // "8 or more" backward possible | "16 or more" forward
+                        "s_cmp_eq_u32 %[t1], 0\n\t"
+                        "s_cbranch_scc0 4f\n"
+                        "8:\n\t"
+                        "s_bitset1_b64 %[ev], %[e]\n\t"             // a match is found at this probe (:406-407)
+                        "s_bfe_u32 %[Brel], %[inf], 0x70017\n\t"
+                        "s_bfe_u32 %[e], %[inf], 0x60010\n\t"
+                        "s_cbranch_scc1 9b\n\t"
+                        "s_branch 10b\n"
+                        "4:\n\t"
+                        "s_bitcmp1_b32 %[inf], 9\n\t"
+                        "s_cbranch_scc1 2f\n\t"                     // forward "16 or more": extend in C++
+                        "s_sub_i32 %[t1], %[e], %[Brel]\n\t"
+                        "s_cmp_ge_i32 %[t1], 8\n\t"
+                        "s_cbranch_scc0 8b\n"                        // fewer than 8 pending literals: the backward part is exact
+                        "2:\n\t"
+                        "s_mov_b32 %[np], %[e]\n\t"
+                        "s_mov_b32 %[slow], 1\n"
+                        "3:\n\t"
+                        : [Brel] "+s"(Brel), [np] "+s"(np), [ev] "+s"(evmask), [slow] "+s"(slow), [inf] "=&s"(inf),
+                          [t1] "=&s"(t1), [t2] "=&s"(t2), [tmp] "=&s"(tmp), [e] "=&s"(e)
+                        : [winfo] "v"(winfo), [A] "s"(Amask)
+                        : "scc");
+                };
+                walk();
+                while (__builtin_expect(slow != 0, 0)) {
+                    // one token with a length of "8 or more" backward or "16 or more" forward, at lane np
+                    const int e = (int)np;
+                    const uint32_t qe = base + (uint32_t)e;
+                    uint32_t fwd = readlane(fwd8, e);
+                    const uint32_t pe = (uint32_t)(e - Brel);                // j - backRefEnd (:404)
+                    const uint32_t bre = readlane(broom, e);
+                    uint32_t bw = bre < pe ? bre : pe;
+                    {
+                        const int32_t ce = (int32_t)readlane((uint32_t)c, e);
+                        if (fwd == 16) fwd = l1p_extend_match(TS, qe, ce, ZZ_MAX_LEN, 16);    // remain(), :64-90
+                        const uint32_t re = readlane(room, e);
+                        const uint32_t blim = re < pe ? re : pe;
+                        if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
+                    }
+                    uint32_t mlen = fwd + bw;
+                    if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                           // :412-415
+                    const uint32_t ms = qe - bw;                                                        // :416
+                    Brel = (int32_t)(ms + mlen - base);                                                 // :422
+                    if (lane == e) tk = ms | (mlen << 16);                                              // :420
+                    evmask |= 1ull << e;
+                    slowmask |= 1ull << e;
+                    np = (uint32_t)Brel + 1;                                                            // :424
+                    slow = 0;
+                    if (np < 64) walk();
+                }
+                B = base + (uint32_t)Brel;
+                nextProbe = base + np;
+                // the parser behind is waiting for these two and nothing else: out first
+                if (lane == 0) { xb[0] = B; xb[1] = nextProbe; }
+            }
+            myNext = nextProbe;
+            ZZ_T(2); ZZ_C(11, (uint32_t)__builtin_popcountll(evmask)); ZZ_C(12, (uint32_t)__builtin_popcountll(slowmask));
+            // ---- this block's matches: starts and lengths, their symbols, the covered / match-start bits; one word per match
+            // to the helper (length symbol - 257 [27:23], length extra value [22:18], distance code [17:13], distance extra value [12:0])
+            if (evmask) {
+                const bool slowl = (slowmask >> lane) & 1;
+                uint32_t ms = tk & 0xFFFFu, mlen = tk >> 16;               // as the C++ path left them
+                // matches the scalar loop only marked: backRefEnd after a match is probe + forward length (:416,422); the backward
+                // part is limited by the literals pending since the previous match of this block (or since the block was entered)
+                const uint32_t endp = slowl ? ms + mlen : q + fwd8;
+                const uint64_t prev = evmask & below_me;
+                const int pl = prev ? 63 - __builtin_clzll(prev) : lane;
+                const uint32_t pend_end = (uint32_t)__shfl((int)endp, pl);            // every lane takes part
+                if (!slowl) {
+                    const uint32_t pe = q - (prev ? pend_end : Bentry);
+                    const uint32_t bq = broom < pe ? broom : pe;
+                    ms = q - bq; mlen = fwd8 + bq;
+                }
+                if ((evmask >> lane) & 1) {
+                    const uint32_t dist = (uint32_t)((int32_t)q - c);
+                    uint32_t sym, leb, lev, bucket, deb, dev;            // GetFrequencies, :455-463
+                    length_symbol(mlen, sym, leb, lev);
+                    dist_symbol(dist, bucket, deb, dev);
+                    slot[lane] = ((sym - 257) << 23) | (lev << 18) | (bucket << 13) | dev;
+                    // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
+                    const uint32_t last = ms + mlen - 1;
+                    const uint32_t w0 = ms >> 6, w1 = last >> 6;
+                    const uint64_t from_lo = ~0ull << (ms & 63), to_hi = ~0ull >> (63u - (last & 63));
+                    atomicOr((unsigned long long*)&covw[w0 & (ZZ_L2_WIN - 1)], (unsigned long long)(w1 == w0 ? (from_lo & to_hi) : from_lo));
+                    if (w1 != w0) {
+                        atomicOr((unsigned long long*)&covw[w1 & (ZZ_L2_WIN - 1)], (unsigned long long)to_hi);
+                        for (uint32_t wi = w0 + 1; wi < w1; ++wi) atomicOr((unsigned long long*)&covw[wi & (ZZ_L2_WIN - 1)], ~0ull);
+                    }
+                    atomicOr((unsigned long long*)&mstw[(ms >> 6) & (ZZ_L2_WIN - 1)], 1ull << (ms & 63));
+                }
+            }
+            slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32);     // (the same words from all lanes: no lane mask to set up)
+            wa = wan; wa2 = wan2; wb = wbn;
+            ZZ_T(3);
+            l2_block_barrier();                                           // B_g+1: this block has been walked
+            ZZ_T(4);
+            if (ZZ_L2P_PRIO_W != ZZ_L2P_PRIO_P) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
+        };
+        if (g >= 1 && !sw && base + 64 <= batchEnd) block(std::true_type{});
+        else block(std::false_type{});
+    }
+    if (gs < NB && gs + 1 >= NB && pw == 1) l2_block_barrier();          // Bx, where the switch block is the packet's last
+    if (((NB - 1) & 1u) != pw) l2_block_barrier();                       // B_NB: the other parser's last walk (NB = 0: B0)
+#ifdef ZZ_PROF
+    if (lane == 0 && prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&prof[16 * (1 + pw) + _i], prof_acc[_i]);
+#endif
+    (void)prof;
+}
+
+// The helper wavefront's side: per block the parsers' match words go to the packet's scratch and into the symbol counts, and the
+// block that can no longer change is turned into records (zz_level2.h, l2_helper_pass: everything else is the walker's now).
+__device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
+                                                    uint32_t* tokens, uint16_t* recs, const uint8_t* src, uint32_t n,
+                                                    uint32_t& nrec_out, uint32_t& adA, uint64_t& adC, unsigned long long* prof = nullptr)
+{
+    const int lane = lane_id();
+    ZZ_PROF_DECL
+    const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;
+    const uint32_t trips = (target + 63) >> 6;
+    const uint32_t gs = l2p_switch_block(target);
+    uint32_t nrec = 0, Fnext = 0, ntok = 0;
+    adA = 0; adC = 0;
+    l2_block_barrier();                                                  // B0
+    for (uint32_t i = 0; i < trips; ++i) {
+        const uint32_t base = i << 6;
+        uint32_t fbyte = 0;
+        if (i >= ZZ_L2_LAG) {
+            const uint32_t p = base + lane - 64 * ZZ_L2_LAG;        // < n: the probe front is at least 258 bytes from the end
+            fbyte = src[p];
+            adA += fbyte; adC += (uint64_t)p * fbyte;
+        }
+        ZZ_T(1); ZZ_C(10, 1);
+        if (i == gs) l2_block_barrier();                                 // Bx
+        l2_block_barrier();                                              // B_i+1: block i has been walked
+        ZZ_T(0);
+        const uint32_t* slot = hb + (i & 1) * ZZ_L2_HB_WORDS;
+        const uint32_t tok = slot[lane];
+        const uint64_t evmask = ((uint64_t)uniform(slot[65]) << 32) | uniform(slot[64]);
+        if (evmask) {
+            if ((evmask >> lane) & 1) {
+                tokens[ntok + mbcnt(evmask)] = tok;
+                hist_add(histP, 257 + (tok >> 23));
+                hist_add(histP, 286 + ((tok >> 13) & 31));
+            }
+            ntok += (uint32_t)__builtin_popcountll(evmask);
+        }
+        // later matches start at >= base + 64 - 258: block (base>>6) - 5 cannot change any more
+        if (i >= ZZ_L2_LAG) {
+            ZZ_WAVE_SYNC();
+            nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, fbyte);
+            Fnext++;
+        }
+    }
+    ZZ_WAVE_SYNC();
+    for (const uint32_t nblk = (n + 63) >> 6; Fnext < nblk; ++Fnext) {       // the tail nobody probes (:222) + the lag
+        const uint32_t p = (Fnext << 6) + (uint32_t)lane;
+        const uint32_t d = p < n ? src[p] : 0u;
+        adA += d; adC += (uint64_t)p * d;
+        nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, d);
+    }
+    nrec_out = nrec;
+#ifdef ZZ_PROF
+    if (lane == 0 && prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&prof[48 + _i], prof_acc[_i]);
+#endif
+    (void)prof;
+    return ntok;
+}
+
+}  // namespace zz
