@@ -665,7 +665,8 @@ def main():
         l1_two = l1_two or (args.level == 1 and bool(args.warm) and not classic)
         scal = tj_scalar if (args.level == 1 and l1_two) or args.level in (2, 3) else None
         if insts and kms > 0 and args.level >= 1:
-            resident = 256 * (8 if args.level >= 4 else 9) * (3 if l1_two else 2)     # k_encode_l1p: two parsers + the emitter per packet
+            l2_two = args.level in (2, 3) and not args.warm and os.environ.get("ZZFLATE_L2_KERNEL") != "classic"
+            resident = 256 * (8 if args.level >= 4 else 9) * (3 if (l1_two or l2_two) else 2)     # k_encode_l1p / k_encode_l2p: two parsers + the emitter / helper per packet
             cpi, ghz = 5.0, 2.4
             bound_ms = insts * cpi / (resident * ghz * 1e9) * 1e3
             issue = {"bound": "issue", "instructions": insts, "cycles_per_instruction": cpi, "resident_wavefronts": resident,
@@ -697,7 +698,9 @@ def main():
             "calls_in_flight": len(lanes) if (not multi) else None,
             "exchange": exchange if multi else None,
             "roofline": {
-                "bound": "hbm", "kernel": ("k_l6_matches + k_encode_l2_t" if args.level >= 4 else "k_encode_l2_t" if args.level >= 2
+                "bound": "hbm", "kernel": ("k_l6_matches + k_encode_l2_t<32768, true>" if args.level >= 4 else
+                                           ("k_encode_l2_t<32768, false>" if args.warm else "k_encode_l2_t<0, false>" if os.environ.get("ZZFLATE_L2_KERNEL") == "classic"
+                                            else "k_encode_l2_t<0, false, true> (k_encode_l2p)") if args.level >= 2
                                            else l1_kernel if args.level == 1 else "k_encode_l0"),
                 "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,

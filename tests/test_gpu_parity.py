@@ -646,6 +646,18 @@ def test_lds_order_violation_seen_by_the_kernel_reruns_the_call(gpu, oracle, cor
     assert zz.lib.zz_debug_lds_order_verdict(0) == 1 and zz.lib.zz_debug_l1_kernel(ctx._h) == 2
 
 
+@pytest.mark.parametrize("args", [("1,2,3", "0"), ("1", "32768")], ids=["cold", "warm"])
+def test_one_parser_kernels_stay_bit_exact(args):
+    """k_encode_l1 / k_encode_l1w / k_encode_l2_t<0, false> are what ZZFLATE_L1_KERNEL=classic / ZZFLATE_L2_KERNEL=classic launch
+    (A/B runs; k_encode_l1 is also the fallback behind the LDS-order check) now that the two-parser kernels are the default: the
+    switches are read once per process, so a child process runs tests/gpu_quick.py (corpus files and synthetic edge sizes against
+    the oracle) with both set."""
+    import subprocess, sys
+    env = dict(os.environ, ZZFLATE_L1_KERNEL="classic", ZZFLATE_L2_KERNEL="classic")
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "tests", "gpu_quick.py"), *args], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_extended_levels_and_warm_window_at_level2(gpu, oracle, corpus):
     """levels 4, 5, 6 (off unless switched on) = hash chains of depth 2 / 4 / 8 over a window of 8 / 32 /
     32 KiB, one-step lazy matching, package-merge code lengths (zz_level6.h). Bit-exact with the oracle's definition

@@ -66,7 +66,7 @@ def main():
         f = out.get(fetch, {}).get(kern, {}).get("FETCH_SIZE"); w = out.get(write, {}).get(kern, {}).get("WRITE_SIZE")
         return int((2 * f + w) * 1024) if f is not None and w is not None else None
     traffic["level1_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l1p")
-    traffic["level2_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l2_t<0u, false>")
+    traffic["level2_text_1024MiB"] = t("fetch_l1", "write_l1", "zz::k_encode_l2_t<0u, false, true>")
     traffic["level0_random_1024MiB"] = t("fetch_l0", "write_l0", "zz::k_encode_l0")
     # wave-level instructions per launch (SQ_INSTS_*): what the issue-rate bound in bench.py's roofline is computed from
     def insts(run, kern):
@@ -74,13 +74,13 @@ def main():
         keys = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")
         return int(sum(c[k] for k in keys)) if all(k in c for k in keys) else None
     traffic["instructions_level1_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l1p")
-    traffic["instructions_level2_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l2_t<0u, false>")
+    traffic["instructions_level2_text_1024MiB"] = insts("sq_l1", "zz::k_encode_l2_t<0u, false, true>")
     # the CU's one scalar unit: SALU + branch instructions per launch (bench.py roofline.scalar)
     def scalar(run, kern):
         c = out.get(run, {}).get(kern, {})
         return int(c["SQ_INSTS_SALU"] + c["SQ_INSTS_BRANCH"]) if "SQ_INSTS_SALU" in c and "SQ_INSTS_BRANCH" in c else None
     traffic["scalar_instructions_level1_text_1024MiB"] = scalar("sq_l1", "zz::k_encode_l1p")
-    traffic["scalar_instructions_level2_text_1024MiB"] = scalar("sq_l1", "zz::k_encode_l2_t<0u, false>")
+    traffic["scalar_instructions_level2_text_1024MiB"] = scalar("sq_l1", "zz::k_encode_l2_t<0u, false, true>")
     traffic["git_sha"] = a.git_sha
     traffic["source_sha256"] = source_hash()
     json.dump(traffic, open(os.path.join(a.dest, "traffic.json"), "w"), indent=1)

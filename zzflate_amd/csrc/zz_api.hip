@@ -224,7 +224,8 @@ extern "C" int zz_debug_occupancy(int level)
     if (level == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1p, ZZ_L1P_THREADS, 0);
     else if (level == -1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l1, ZZ_L1_THREADS, 0);
     else if (level >= 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<32768u, true>, ZZ_L2_THREADS, 0);
-    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, false>, ZZ_L2_THREADS, 0);
+    else if (level >= 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, false, true>, ZZ_L2P_THREADS, 0);
+    else if (level == -2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l2_t<0u, false>, ZZ_L2_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_encode_l0, 256, 0);
     return nb;
 }

@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
     // hand-over slots (used during it); the bitmap window and the packed counters have their own.
     constexpr uint32_t HB = XD ? 12288u : 16384u;                 // where the part behind the hash table starts (XD: behind the helper's bit ring at 11520)
     constexpr uint32_t RING2 = 11520u;                            // the helper's bit ring of the emission
+    constexpr uint32_t RING3 = 12288u;                            // PP: the second parser's (the dead hash table has room: 12080 .. 16384)
     __shared__ __attribute__((aligned(16))) uint8_t lds[HB + (ZZ_L2_LDS_BYTES - 16384) + 16];
     uint16_t* T = (uint16_t*)lds;                                 // 16384: hash table during the token pass
     uint32_t* symF = (uint32_t*)(lds + 8192);                     // 1280: 286 lit/len + pad | 30 dist at [288..318)
@@ -1130,10 +1131,10 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                 // two parsers: B0 also says "the table is clear" to the second one, "window and counters are" to both
                 if (W0) {
                     if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
-                    l2p_token_pass(T, hb, xb, covw, mstw, src, end, l1p_make_src(P, src, end), n, before, 0u, P.prof);
+                    l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 0u, P.prof);
                     if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(3);
                 }
-                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, src, end, l1p_make_src(P, src, end), n, before, 1u, P.prof);
+                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 1u, P.prof);
             } else if (W0) {
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
@@ -1167,11 +1168,42 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
         }
         uint32_t* share = misc + 4;      // [0] 1 stored / 2 dynamic, [1] first record of the helper's part, [2] bits in front of
                                          // the records, [3] wavefront 0's last (partial) word, [4] the helper's first word
+                                         // PP: [5] first record of the second parser's part, [6] the helper's last (partial) word,
+                                         // [7] the second parser's first word, [8] index of the word the first two parts share
         if (PB) {
-            // the second parser has no part in the rest of the packet: it keeps the barriers
+            // PP: the body goes out in THREE parts -- wavefront 0 the records [0, r1), the helper [r1, r2), this wavefront [r2, nbody),
+            // the end of the block and the end of the packet. A part's place in the bit stream follows from a dry run over the records
+            // in front of it; the words two parts share are put together here at the end.
             if (n > 0) {
-                __syncthreads();             // (X)
-                if (uniform(share[0]) == 2) __syncthreads();      // (Y)
+                __syncthreads();             // (X) codes are ready, or the block went out stored
+                if (uniform(share[0]) == 2) {
+                    const uint32_t nbody = (uint32_t)covw[0], r2 = uniform(share[5]);
+                    uint32_t m2 = 0;
+                    const uint32_t bits2 = l2_count_bits(recs, tokens, codes, dcodes, r2, m2);
+                    bitring ring3;
+                    ring_init_at(ring3, (uint32_t*)(lds + RING3), out, uniform(share[2]) + bits2, share + 7);
+                    l2_emit_records(ring3, recs, tokens, codes, dcodes, r2, nbody, m2);
+                    {   // codes[256] (:300)
+                        const uint32_t cd = codes[256];
+                        ring_append_uniform64(ring3, cd & 0xFFFF, cd >> 16);
+                    }
+                    if (!is_final) {
+                        // one stored byte = byte alignment (zzflate.cpp:118-120)
+                        ring_append_uniform64(ring3, 0, 3);
+                        ring_pad_to_byte(ring3);
+                        ring_append_uniform64(ring3, 0xFFFE0001u, 32);
+                        ring_append_uniform64(ring3, src[len - 1], 8);
+                    }
+                    const uint32_t bytes = ring_finish_hold(ring3);
+                    __syncthreads();         // (Y) the other parts' boundary words are in `share`
+                    if (lane == 0) {
+                        const uint32_t iA = share[8], iB = ring3.hold;
+                        if (iA == iB) ring3.out32[iB] = share[3] | share[4] | share[6] | share[7];     // (the helper's part began and ended in one word)
+                        else { ring3.out32[iA] = share[3] | share[4]; ring3.out32[iB] = share[6] | share[7]; }
+                        P.sizes[k] = bytes;
+                        if (bytes > P.slot_stride) atomicOr(P.err, 1u);
+                    }
+                }
             }
             return;
         }
@@ -1190,6 +1222,18 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                     const uint32_t bits1 = l2_count_bits(recs, tokens, codes, dcodes, r1, m1);
                     bitring ring2;
                     ring_init_at(ring2, (uint32_t*)(lds + RING2), out, uniform(share[2]) + bits1, share + 4);
+                    if (PP) {
+                        // the middle part: its first word is held back like the last part's, its last (partial) word is handed on
+                        const uint32_t r2 = uniform(share[5]);
+                        l2_emit_records(ring2, recs, tokens, codes, dcodes, r1, r2, m1);
+                        ZZ_WAVE_SYNC();
+                        if (lane == 0) {
+                            share[6] = (ring2.bitpos & 31) ? ring2.ring[(ring2.bitpos >> 5) & (ZZ_RING_WORDS - 1)] : 0u;
+                            share[8] = ring2.hold;
+                        }
+                        __syncthreads();     // (Y)
+                        return;
+                    }
                     l2_emit_records(ring2, recs, tokens, codes, dcodes, r1, nbody, m1);
                     {   // codes[256] (:300)
                         const uint32_t cd = codes[256];
@@ -1315,8 +1359,12 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             // body: both wavefronts emit. This one takes the records [0, r1), the helper the rest and everything behind
             // them; the word the two parts share is put together by the helper at the end.
             {
-                const uint32_t r1 = ((nbody * ZZ_L2_SPLIT64) >> 6) & ~63u;   // a little more than half: the helper also has a dry run to do
-                if (lane == 0) { share[0] = 2; share[1] = r1; share[2] = ring.bitpos; }
+                // (two parts: a little more than half here, the helper also has a dry run to do; PP: three parts, each later one with
+                // a longer dry run in front of it)
+                const uint32_t r1 = PP ? ((nbody * ZZ_L2P_SPLIT1) >> 6) & ~63u : ((nbody * ZZ_L2_SPLIT64) >> 6) & ~63u;
+                uint32_t r2 = ((nbody * ZZ_L2P_SPLIT2) >> 6) & ~63u;
+                if (r2 < r1) r2 = r1;
+                if (lane == 0) { share[0] = 2; share[1] = r1; share[2] = ring.bitpos; if (PP) { share[4] = 0; share[5] = r2; share[7] = 0; } }
                 __syncthreads();             // (X)
                 l2_emit_records(ring, recs, tokens, codes, dcodes, 0, r1, 0);
                 ZZ_WAVE_SYNC();

@@ -36,7 +36,26 @@ namespace zz {
 #define ZZ_L2P_PRIO_W 3
 #endif
 #ifndef ZZ_L2P_PRIO_P
-#define ZZ_L2P_PRIO_P 3
+#define ZZ_L2P_PRIO_P 1
+#endif
+#ifndef ZZ_L2P_PRIO_H
+#define ZZ_L2P_PRIO_H 0         // ... and of the helper during the token pass
+#endif
+// who counts a match's length and distance symbols: 0 = the helper (from the match word), 1 = the walker (it has them at hand)
+#ifndef ZZ_L2P_HIST_W
+#define ZZ_L2P_HIST_W 0
+#endif
+// where the walk's packed word per lane (hop pointers, flags) is put together: 0 = in front of the barrier (the prober's side), 1 = behind it
+#ifndef ZZ_L2P_WINFO_W
+#define ZZ_L2P_WINFO_W 0
+#endif
+// the body's three parts in 64ths of the records: wavefront 0 takes [0, SPLIT1), the helper [SPLIT1, SPLIT2), the second parser the
+// rest; a dry run over a record costs about 0.4 of emitting it, so equal finishing times want 0.51 / 0.31 / 0.18
+#ifndef ZZ_L2P_SPLIT1
+#define ZZ_L2P_SPLIT1 33u
+#endif
+#ifndef ZZ_L2P_SPLIT2
+#define ZZ_L2P_SPLIT2 52u
 #endif
 #define ZZ_L2P_SWITCH_BLOCK (ZZ_BATCH_LEN / ZZ_WAVE)      // block 256: where the second batch starts (if the search region reaches it)
 
@@ -45,7 +64,7 @@ __device__ __forceinline__ uint32_t l2p_switch_block(uint32_t target) { return t
 
 // One parsing wavefront (pw = 0: even blocks, 1: odd blocks). xb: [0] backRefEnd, [1] the next probe position, as the walk
 // of the block walked last left them. Barriers: see above; every wavefront of the workgroup executes B0 .. B_NB (+ Bx).
-__device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32_t* xb, uint64_t* covw, uint64_t* mstw, const uint8_t* src,
+__device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32_t* xb, uint64_t* covw, uint64_t* mstw, uint32_t* histP, const uint8_t* src,
                                                const uint8_t* end, const l1p_src& TS, const uint32_t n, const uint64_t before, const uint32_t pw,
                                                unsigned long long* prof = nullptr)
 {
@@ -90,6 +109,17 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
             if (lane == 0) { xb[0] = s2 + 1; xb[1] = s2 + 1; }
             myNext = s2 + 1;
         }
+        // the walk's word per lane: fwd8 [4:0], need [7:5], "8 or more backward possible" bit 8, "16 or more forward" bit 9, plain bit 10,
+        // strong bit 11, next candidate [21:16] (0 = none), lane + fwd8 [29:23] (zz_level2.h, ZZ_L2_HOP)
+        auto make_winfo = [&](uint32_t fwd8, uint32_t broom, uint64_t Amask) -> uint32_t {
+            const uint32_t inexact = (fwd8 & 16u) | (broom & 8u);
+            uint32_t winfo = fwd8 | (sub_from4_sat(fwd8) << 5) | (inexact << 5) | (((fwd8 + 28u) & 32u) << 6) |
+                             ((fwd8 >= 4 && inexact == 0) ? 0x400u : 0u) | (((uint32_t)lane + fwd8) << 23);
+            const uint32_t endl = (uint32_t)lane + fwd8 + 1;                  // first lane probed after a match here
+            const uint64_t m = Amask >> (endl & 63u);
+            const uint32_t nx = endl + (m ? (uint32_t)__builtin_ctzll(m) : 64u);
+            return winfo | (((nx < 64u ? nx : 64u) & 63u) << 16);             // (64 & 63 = 0 = none)
+        };
         auto block = [&](auto interior_tag) {
             // INTERIOR: not the packet's first block, not the switch block, every position inside the current batch
             constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -169,15 +199,7 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                 broom = bwd8 < room ? bwd8 : room;
                 if (!has) broom = 0;
                 Amask = ballot(fwd8 + broom >= 4);                                // strong or weak
-                const uint32_t inexact = (fwd8 & 16u) | (broom & 8u);
-                winfo = fwd8 | (sub_from4_sat(fwd8) << 5) | (inexact << 5) | (((fwd8 + 28u) & 32u) << 6) |
-                        ((fwd8 >= 4 && inexact == 0) ? 0x400u : 0u) | (((uint32_t)lane + fwd8) << 23);
-                {
-                    const uint32_t endl = (uint32_t)lane + fwd8 + 1;              // first lane probed after a match here
-                    const uint64_t m = Amask >> (endl & 63u);
-                    const uint32_t nx = endl + (m ? (uint32_t)__builtin_ctzll(m) : 64u);
-                    winfo |= ((nx < 64u ? nx : 64u) & 63u) << 16;                 // (64 & 63 = 0 = none)
-                }
+                if (!ZZ_L2P_WINFO_W) winfo = make_winfo(fwd8, broom, Amask);
             }
             ZZ_T(0);
             l2_block_barrier();                                           // Bg (the switch block: Bx) -- the block in front has been walked
@@ -186,6 +208,7 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
 
             // ---- W: the greedy walk (zz_level2.h: the same scalar loop) ----------------------------------------------------------
             uint32_t B = uniform(xb[0]), nextProbe = uniform(xb[1]);
+            if (ZZ_L2P_WINFO_W) winfo = make_winfo(fwd8, broom, Amask);
             const bool doProbe = base + 64 > nextProbe && nextProbe < batchEnd;   // some position of this block is probed
             uint32_t* slot = hb + (g & 1u) * ZZ_L2_HB_WORDS;
             uint64_t evmask = 0, slowmask = 0;
@@ -303,6 +326,7 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                     length_symbol(mlen, sym, leb, lev);
                     dist_symbol(dist, bucket, deb, dev);
                     slot[lane] = ((sym - 257) << 23) | (lev << 18) | (bucket << 13) | dev;
+                    if (ZZ_L2P_HIST_W) { hist_add(histP, sym); hist_add(histP, 286 + bucket); }
                     // covered / start bits: words (base>>6)-5 .. (base>>6)+5 of the LDS window
                     const uint32_t last = ms + mlen - 1;
                     const uint32_t w0 = ms >> 6, w1 = last >> 6;
@@ -346,6 +370,7 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
     const uint32_t gs = l2p_switch_block(target);
     uint32_t nrec = 0, Fnext = 0, ntok = 0;
     adA = 0; adC = 0;
+    if (ZZ_L2P_PRIO_H) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_H);
     l2_block_barrier();                                                  // B0
     for (uint32_t i = 0; i < trips; ++i) {
         const uint32_t base = i << 6;
@@ -365,8 +390,10 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
         if (evmask) {
             if ((evmask >> lane) & 1) {
                 tokens[ntok + mbcnt(evmask)] = tok;
-                hist_add(histP, 257 + (tok >> 23));
-                hist_add(histP, 286 + ((tok >> 13) & 31));
+                if (!ZZ_L2P_HIST_W) {
+                    hist_add(histP, 257 + (tok >> 23));
+                    hist_add(histP, 286 + ((tok >> 13) & 31));
+                }
             }
             ntok += (uint32_t)__builtin_popcountll(evmask);
         }
@@ -385,6 +412,7 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
         nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, d);
     }
     nrec_out = nrec;
+    if (ZZ_L2P_PRIO_H) __builtin_amdgcn_s_setprio(0);
 #ifdef ZZ_PROF
     if (lane == 0 && prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&prof[48 + _i], prof_acc[_i]);
 #endif
