@@ -35,7 +35,7 @@ static thread_local std::string g_err;
 static void set_err(const std::string& s) { g_err = s; }
 extern "C" const char* zz_last_error(void) { return g_err.c_str(); }
 extern "C" const char* zz_version(void) { return "zzflate_amd 0.1 (gfx950)"; }
-// Compile-time switches this binary was built with, as a space-separated list; "" for the product build. The first three write
+// Compile-time switches this binary was built with, as a space-separated list; "" for the product build. The ZZ_*_X_* ones and the probe write
 // WRONG STREAMS (timing experiments: tools/pipe_probe.sh, tools/units_probe.sh); ZZ_PROF adds cycle stamps; the last one is the
 // test build libzzflate_amd_careful.so. tests/test_abi.py holds the shipped library to "".
 extern "C" const char* zz_build_flags(void)
@@ -49,6 +49,15 @@ extern "C" const char* zz_build_flags(void)
 #endif
 #ifdef ZZ_L1P_X_NOEMIT
         " ZZ_L1P_X_NOEMIT"
+#endif
+#ifdef ZZ_L1P_X_NOEXT
+        " ZZ_L1P_X_NOEXT"
+#endif
+#ifdef ZZ_L2P_X_NOEXT
+        " ZZ_L2P_X_NOEXT"
+#endif
+#if ZZ_L2P_FLAGS
+        " ZZ_L2P_FLAGS"
 #endif
 #ifdef ZZ_PROF
         " ZZ_PROF"
@@ -638,6 +647,7 @@ static int encode_finish(zz_ctx* c, zz_result* host_res)
         return encode_common(c, q.d_src, q.n, q.halo, q.last_is_final, q.d_dst, q.cap, q.format, q.cks_kind, q.whole, q.level_asked, q.P,
                              q.st, host_res, true);
     }
+    if (c->h_err[0] & 8u) { set_err("internal: a wavefront of the level-2 kernel waited for its neighbour longer than a packet can take (zz_level2p.h, l2p_wait_ge)"); return ZZ_E_HIP; }
     if (c->h_err[0]) { set_err("internal: packet slot overflow"); return ZZ_E_NOSPACE; }
     if (host_res->err) { set_err("destination too small for the compressed stream"); return ZZ_E_NOSPACE; }
     if (c->pend.npk) { c->last.stream_bytes = host_res->stream_bytes; c->have_last = true; }

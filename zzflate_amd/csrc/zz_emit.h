@@ -64,6 +64,51 @@ __device__ __forceinline__ void ring_append(bitring& r, uint32_t bits, uint32_t 
     ring_flush_full(r);
 }
 
+__device__ __forceinline__ void ring_pad_to_byte(bitring& r);
+// The same with the stores batched: completed words leave the ring only once 32 of them are waiting (one coalesced store of up to
+// 64 words instead of one of ~6 per append: level 1's emitter appends ~200 bits per block of text). At most 31 words wait in front
+// of an append and one append adds at most 63 (64 lanes x 31 bits), so one pass of 64 lanes empties the ring far enough and the
+// 128-word ring never wraps onto live words. ring_finish_lazy drains whatever is left.
+__device__ __forceinline__ void ring_append_lazy(bitring& r, uint32_t bits, uint32_t nb)
+{
+    const uint32_t incl = wave_scan_incl(nb);
+    const uint32_t total = readlane(incl, 63);
+    const uint32_t o = r.bitpos + incl - nb;
+    const uint32_t sh = o & 31;
+    const uint32_t w = o >> 5;
+    if (nb) {
+        atomicOr(&r.ring[w & (ZZ_RING_WORDS - 1)], bits << sh);
+        if (sh + nb > 32) atomicOr(&r.ring[(w + 1) & (ZZ_RING_WORDS - 1)], bits >> (32 - sh));
+    }
+    r.bitpos += total;
+    const uint32_t full = r.bitpos >> 5;
+    if (full - r.flushed >= 32u) {
+        ZZ_WAVE_SYNC();
+        const uint32_t upto = full - r.flushed > 64u ? r.flushed + 64u : full;
+        const uint32_t wi = r.flushed + lane_id();
+        if (wi < upto) {
+            const uint32_t v = r.ring[wi & (ZZ_RING_WORDS - 1)];
+            r.ring[wi & (ZZ_RING_WORDS - 1)] = 0;
+            r.out32[wi] = v;
+        }
+        r.flushed = upto;
+        ZZ_WAVE_SYNC();
+    }
+}
+__device__ __forceinline__ uint32_t ring_finish_lazy(bitring& r)
+{
+    ring_pad_to_byte(r);
+    const uint32_t bytes = r.bitpos >> 3;
+    const uint32_t words = (bytes + 3) >> 2;
+    ZZ_WAVE_SYNC();
+    while (r.flushed < words) {                          // (at most two passes: fewer than 96 words wait)
+        const uint32_t w = r.flushed + lane_id();
+        if (w < words) r.out32[w] = r.ring[w & (ZZ_RING_WORDS - 1)];
+        r.flushed += ZZ_WAVE;
+    }
+    return bytes;
+}
+
 // wave-uniform append of up to 32 bits (all lanes pass the same values)
 __device__ __forceinline__ void ring_append_uniform(bitring& r, uint32_t bits, uint32_t nb)
 {

@@ -66,6 +66,10 @@ namespace zz {
 #ifndef ZZ_L1P_ORDER_CHECK
 #define ZZ_L1P_ORDER_CHECK 0
 #endif
+// the emitter's completed words leave the bit ring in batches of 32..64 (zz_emit.h ring_append_lazy) instead of after every block
+#ifndef ZZ_L1P_LAZY_FLUSH
+#define ZZ_L1P_LAZY_FLUSH 1
+#endif
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 #define ZZ_L1P_NONE 64u          // win[]: no lane of the block with that hash was visited
@@ -325,7 +329,12 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     if (mlen >= 4) {
                         if (inf & (useB ? ZZ_WI_EXTB : ZZ_WI_EXTA)) {     // remain(), encoder.cpp:64-90
                             const int32_t cand = useB ? (int32_t)(base + ZZ_WI_QLANE(inf)) : (int32_t)(readlane(told, e) - 1u - BIAS);
+#ifdef ZZ_L1P_X_NOEXT
+                            (void)cand;                                  // TIMING EXPERIMENT (valid but WRONG streams): "16 or more" is 16, no extension loads
+                            mlen = maxlen < ZZ_WI_CAP ? maxlen : ZZ_WI_CAP;
+#else
                             mlen = l1p_extend_match(SRC, pe, cand, maxlen, ZZ_WI_CAP);
+#endif
                             if (lane == e) ovlen = mlen | 0x8000u;
                             ovmL |= 1ull << e;
                         }
@@ -350,7 +359,11 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                     mlen = 0;
                     if ((uint32_t)xe == 0 && maxlen >= 4) {
                         if (xe != 0) mlen = (uint32_t)__builtin_ctzll(xe) >> 3;
+#ifdef ZZ_L1P_X_NOEXT
+                        else mlen = 8;
+#else
                         else mlen = l1p_extend_match(SRC, pe, (int32_t)(cand1 - 1u - BIAS), maxlen);
+#endif
                         if (mlen > maxlen) mlen = maxlen;
                     }
                     if (lane == e) { ovlen = mlen | 0x8000u; ovcand1 = cand1; }
@@ -467,6 +480,11 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
     const int lane = lane_id();
     const l1_pk q = l1_packet_of(P, k);
     bitring ring;
+    // (every append of this wavefront goes the same way: the batched flush must not meet the unbatched one's "at most 64 words wait")
+    auto append_uniform = [&](uint32_t bits, uint32_t nbits) {
+        if (ZZ_L1P_LAZY_FLUSH) ring_append_lazy(ring, lane == 0 ? bits : 0u, lane == 0 ? nbits : 0u);
+        else ring_append_uniform(ring, bits, nbits);
+    };
     if (ZZ_L1P_PRIO_E) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_E);
     ring_init(ring, ring_words, q.out);
     if (BIAS) l1_group_barrier();                                        // B_c
@@ -477,7 +495,7 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
     }
     if (BIAS) l1_group_barrier();                                        // B_z
     if (q.n > 0) {
-        ring_append_uniform(ring, (q.is_final ? 1u : 0u) | (1u << 1), 3);           // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
+        append_uniform((q.is_final ? 1u : 0u) | (1u << 1), 3);           // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
         const uint32_t NB = (q.n + ZZ_WAVE - 1) >> 6;
         const lds_u32* slot = (const lds_u32*)tokbuf + lane;
         l1_group_barrier();                                              // B_0
@@ -492,22 +510,26 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
 #ifdef ZZ_L1P_X_NOEMIT
             if (g == 0)                                                  // TIMING EXPERIMENT: the emitter only keeps the barriers (wrong streams)
 #endif
+#if ZZ_L1P_LAZY_FLUSH
+            { uint32_t bits, nb; l1_token_bits(tok, bits, nb); ring_append_lazy(ring, bits, nb); }
+#else
             l1_emit_tokens(ring, nullptr, tok);
+#endif
         }
-        ring_append_uniform(ring, 0, 7);                                 // EOB: codes_f[256] (encoder.cpp:371)
+        append_uniform(0, 7);                                 // EOB: codes_f[256] (encoder.cpp:371)
         ZZ_PROF_FLUSH_W(P, 2);
     }
     if (!q.is_final) {
         // SetLevel(0); AddData(e-1, e): one stored byte = byte alignment (zzflate.cpp:118-120, encoder.cpp:482-502)
-        ring_append_uniform(ring, 0, 3);
+        append_uniform(0, 3);
         ring_pad_to_byte(ring);
-        ring_append_uniform(ring, 0xFFFE0001u, 32);
-        ring_append_uniform(ring, q.src[q.len - 1], 8);
+        append_uniform(0xFFFE0001u, 32);
+        append_uniform(q.src[q.len - 1], 8);
     } else if (q.n == 0) {
-        ring_append_uniform(ring, 1u | (1u << 1), 3);                    // empty final packet: one empty fixed block (D8)
-        ring_append_uniform(ring, 0, 7);
+        append_uniform(1u | (1u << 1), 3);                    // empty final packet: one empty fixed block (D8)
+        append_uniform(0, 7);
     }
-    const uint32_t bytes = ring_finish(ring);
+    const uint32_t bytes = ZZ_L1P_LAZY_FLUSH ? ring_finish_lazy(ring) : ring_finish(ring);
     if (lane == 0) {
         P.sizes[k] = bytes;
         if (bytes > P.slot_stride) atomicOr(P.err, ZZ_ERR_SLOT_OVERFLOW);

@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
     uint64_t* covw = (uint64_t*)(lds + HB + 560);                 // 128: covered bits of the 16 blocks around the probe front
     uint64_t* mstw = covw + ZZ_L2_WIN;                            // 128: match-start bits
     uint32_t* histP = (uint32_t*)(lds + HB + 560 + 2 * ZZ_L2_WIN * 8);        // 640: packed 16-bit counters
-    __shared__ uint32_t xb[2];                                    // PP: backRefEnd and the next probe position, parser to parser
+    __shared__ uint32_t xb[8];                                    // PP: backRefEnd, the next probe position and the hand-over counters (l2p_sync)
     // Huffman scratch inside the (dead) hash table
     huff_scratch S;
     S.rec_freq = (uint32_t*)(lds);                 // 1152
@@ -1117,6 +1117,12 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             for (int i = lane; i < 2 * ZZ_L2_WIN * 2 + ZZ_L2_HIST_WORDS; i += ZZ_WAVE) zw[i] = 0;   // window + counters
         }
         ZZ_WAVE_SYNC();
+        if (PP && ZZ_L2P_FLAGS) {
+            // the counters the wavefronts meet through during the token pass: cleared here, and one more barrier in front of their first
+            // use (which also says "the table is clear" to the second parser and "window and counters are" to both)
+            if (PB) { if (lane < 8) xb[lane] = lane < 2 ? 1u : 0u; }        // backRefEnd = 1 (:380), j = 1 (:383), nothing walked / entered / handed over
+            __syncthreads();
+        }
         ZZ_T(0);
 
         if (n > 0) {
@@ -1131,10 +1137,10 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                 // two parsers: B0 also says "the table is clear" to the second one, "window and counters are" to both
                 if (W0) {
                     if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
-                    l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 0u, P.prof);
+                    l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 0u, P.err, P.prof);
                     if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(3);
                 }
-                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 1u, P.prof);
+                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 1u, P.err, P.prof);
             } else if (W0) {
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             if (!W0 && !PB) {
                 uint32_t nb = 0, adA = 0;
                 uint64_t adC = 0;
-                const uint32_t nt = PP ? l2p_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, P.prof)
+                const uint32_t nt = PP ? l2p_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, xb, P.err, P.prof)
                                        : l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, XD ? l6_trips(n) : l2_probe_blocks(n));
                 if (lane == 0) { covw[0] = ((uint64_t)nt << 32) | nb; }       // the window is dead now
                 if (P.cks_kind == ZZ_CKS_ADLER) {

@@ -49,6 +49,11 @@ namespace zz {
 #ifndef ZZ_L2P_WINFO_W
 #define ZZ_L2P_WINFO_W 0
 #endif
+// the walk's out-of-line token: 1 = forward and backward extension in one memory round trip (l2p_extend_both), 0 = one after the other
+// (measured: 1 is 0.3 % slower on text and 0.7 % on the mix -- profiles/r05_ab_l2p_extension_and_priorities_*.txt; kept for the record)
+#ifndef ZZ_L2P_EXT_BOTH
+#define ZZ_L2P_EXT_BOTH 0
+#endif
 // the body's three parts in 64ths of the records: wavefront 0 takes [0, SPLIT1), the helper [SPLIT1, SPLIT2), the second parser the
 // rest; a dry run over a record costs about 0.4 of emitting it, so equal finishing times want 0.51 / 0.31 / 0.18
 #ifndef ZZ_L2P_SPLIT1
@@ -59,15 +64,96 @@ namespace zz {
 #endif
 #define ZZ_L2P_SWITCH_BLOCK (ZZ_BATCH_LEN / ZZ_WAVE)      // block 256: where the second batch starts (if the search region reaches it)
 
+// ZZ_L2P_FLAGS = 1: the three wavefronts meet through counters in LDS instead of one s_barrier per block. With the barrier a block's
+// interval is walk + symbols on one side and enter + compare on the other, and the next walk starts behind BOTH; with the counters
+// the next walk starts as soon as backRefEnd and the probe position are out, and the symbols, the bits and the hand-over run
+// beside it. A wait polls its counter (one LDS read, s_sleep between reads) and is bounded: a wait that runs out reports
+// ZZ_ERR_SYNC_TIMEOUT and lets everybody pass (the stream is then refused by the host), so no wavefront can spin for good.
+// Measured (profiles/r05_ab_l2p_counters_instead_of_barriers_*.txt): bit-exact, level 2 text 89.5 -> 84.1 GB/s, level 3 mix 75.5 -> 75.9:
+// a wavefront asleep in s_barrier costs nothing, a polling one takes issue slots from the eight packets beside it (round 1 found
+// the same for a polling emitter at level 1). Off; kept as the measured alternative.
+#ifndef ZZ_L2P_FLAGS
+#define ZZ_L2P_FLAGS 0
+#endif
+#define ZZ_ERR_SYNC_TIMEOUT 8u
+struct l2p_sync {
+    uint32_t B, nextProbe;      // backRefEnd and the next probe position as the walk of block `walked - 1` left them
+    uint32_t walked;            // blocks walked
+    uint32_t entered;           // blocks entered into the table
+    uint32_t tok[2];            // per hand-over slot: 1 + the block whose match words (and covered / start bits) are in place
+    uint32_t cons;              // blocks the helper has picked up
+    uint32_t pad;
+};
+__device__ __forceinline__ void l2p_wait_ge(uint32_t* f, uint32_t need, uint32_t* err)
+{
+    volatile lds_u32* vf = (volatile lds_u32*)f;
+    if (uniform(*vf) >= need) return;
+    for (uint32_t spins = 0;; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if (uniform(*vf) >= need) return;
+        if (spins > (1u << 16)) {                      // ~10 ms: nothing in a packet takes that long
+            *vf = 0x7FFFFFF0u;
+            if (lane_id() == 0) atomicOr(err, ZZ_ERR_SYNC_TIMEOUT);
+            return;
+        }
+    }
+}
+
 // the switch block of a packet whose search region is [0, target), or ~0: none
 __device__ __forceinline__ uint32_t l2p_switch_block(uint32_t target) { return target > ZZ_BATCH_LEN ? ZZ_L2P_SWITCH_BLOCK : 0xFFFFFFFFu; }
+
+// The walk's out-of-line token: a forward length of "16 or more" (remain(), encoder.cpp:64-90) and / or a backward length of "8 or
+// more" (countMatchBackward, :92-102) measured by the whole wavefront, four bytes per lane -- l1p_extend_match and wave_extend_back
+// (zz_level1.h, zz_level2.h) in ONE memory round trip: both pairs of loads go out before either result is looked at. On the mix
+// such a token comes 0.35 times per block and was 4,400 cycles of the walker's time.
+__device__ __forceinline__ void l2p_extend_both(const l1p_src& TS, const uint8_t* src, uint32_t qe, int32_t ce, bool need_f, bool need_b,
+                                                uint32_t blim, uint32_t& fwd, uint32_t& bw)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t of = 16 + 4 * lane, ob = 8 + 4 * lane;
+    const bool actf = need_f && of < ZZ_MAX_LEN, actb = need_b && ob < blim;
+    uint32_t df = 0, db = 0;
+    if (actf) df = load32(l1p_addr<true>(TS, (int32_t)(qe + of))) ^ load32(l1p_addr<true>(TS, ce + (int32_t)of));
+    if (actb) {
+        // (the caller guarantees ce - blim >= the start of readable memory; a 4-byte load may reach up to 3 bytes below that: byte-wise there)
+        if (ob + 4 <= blim) db = load32(src + (int64_t)qe - ob - 4) ^ load32(src + (int64_t)ce - ob - 4);
+        else {
+            for (uint32_t i = 0; i < 4; ++i)
+                if (ob + i < blim) db |= (uint32_t)(src[(int64_t)qe - ob - 1 - i] ^ src[(int64_t)ce - ob - 1 - i]) << (8 * (3 - i));
+        }
+    }
+    if (need_f) {
+        const uint64_t neq = ballot(actf && df != 0);
+        uint32_t len = ZZ_MAX_LEN;
+        if (neq) {
+            const int k = __builtin_ctzll(neq);
+            const uint32_t dk = readlane(df, k);
+            len = 16 + 4 * (uint32_t)k + ((uint32_t)__builtin_ctz(dk) >> 3);
+            if (len > ZZ_MAX_LEN) len = ZZ_MAX_LEN;
+        }
+        fwd = len;
+    }
+    if (need_b) {
+        const uint64_t neq = ballot(actb && db != 0);
+        uint32_t len = blim;
+        if (neq) {
+            const int k = __builtin_ctzll(neq);
+            const uint32_t dk = readlane(db, k);
+            len = 8 + 4 * (uint32_t)k + ((uint32_t)__builtin_clz(dk) >> 3);   // top byte = nearest
+            if (len > blim) len = blim;
+        }
+        bw = len;
+    }
+}
 
 // One parsing wavefront (pw = 0: even blocks, 1: odd blocks). xb: [0] backRefEnd, [1] the next probe position, as the walk
 // of the block walked last left them. Barriers: see above; every wavefront of the workgroup executes B0 .. B_NB (+ Bx).
 __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32_t* xb, uint64_t* covw, uint64_t* mstw, uint32_t* histP, const uint8_t* src,
                                                const uint8_t* end, const l1p_src& TS, const uint32_t n, const uint64_t before, const uint32_t pw,
-                                               unsigned long long* prof = nullptr)
+                                               uint32_t* err, unsigned long long* prof = nullptr)
 {
+    l2p_sync* const S = (l2p_sync*)xb;     // (xb[0], xb[1] are S->B, S->nextProbe)
+    (void)S; (void)err;
     const int lane = lane_id();
     ZZ_PROF_DECL
     const uint64_t below_me = (1ull << lane) - 1, above_me = ~((2ull << lane) - 1);
@@ -88,12 +174,16 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
         }
     }
     uint32_t myNext = 1;            // the next probe position as this wavefront knew it last: a lower bound of the true one
+#if !ZZ_L2P_FLAGS
     if (pw == 0 && lane == 0) { xb[0] = 1; xb[1] = 1; }               // backRefEnd (:380), j (:383)
     if (pw == 1) l2_block_barrier();                                  // B0
+#endif
     for (uint32_t g = pw; g < NB; g += 2) {
         const uint32_t base = g << 6;
         const bool sw = g == gs;
+#if !ZZ_L2P_FLAGS
         if (g == ZZ_L2P_SWITCH_BLOCK + 1 && gs == ZZ_L2P_SWITCH_BLOCK) l2_block_barrier();   // Bx: the switch block's entries are in the table
+#endif
         uint32_t skipPos = 0xFFFFFFFFu;
         // blocks behind the switch belong to the second batch, which ends where the search region ends: a packet's rest is shorter
         // than a batch (s2 >= 16384, target <= 32509); a match that overruns batch AND region leaves nothing to probe (nextProbe > target)
@@ -101,7 +191,11 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
         if (sw) {
             // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first byte is entered only if
             // the last match covered it. Needs the walk of block g - 1: this block's P runs behind Bg, and Bx follows it.
+#if ZZ_L2P_FLAGS
+            l2p_wait_ge(&S->walked, g, err);
+#else
             l2_block_barrier();                                       // Bg
+#endif
             const uint32_t Bw = uniform(xb[0]);
             const uint32_t s2 = Bw > batch1 ? Bw : batch1;
             skipPos = Bw >= batch1 ? 0xFFFFFFFFu : batch1;
@@ -124,6 +218,9 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
             // INTERIOR: not the packet's first block, not the switch block, every position inside the current batch
             constexpr bool INTERIOR = decltype(interior_tag)::value;
             ZZ_T(5); ZZ_C(10, 1);
+#if ZZ_L2P_FLAGS
+            l2p_wait_ge(&S->entered, g, err);                             // the block in front is in the table
+#endif
             const uint32_t q = base + (uint32_t)lane;
             const bool ins = INTERIOR ? true : (q != skipPos && q != 0);
             // (a block that a match found two blocks ago covers entirely is entered but not compared: myNext is a lower bound)
@@ -167,6 +264,9 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                 } else if (ins && W != (uint32_t)lane && (set & above_me) == 0) T[h] = (uint16_t)(q + 1);
             }
             ZZ_WAVE_SYNC();
+#if ZZ_L2P_FLAGS
+            S->entered = g + 1;                                           // (behind the stores above: the LDS takes a wavefront's instructions in order)
+#endif
 
             // ---- quick compare info for all 64 probes of this block (zz_level2.h, l2_token_pass) ---------------------------
             uint32_t fwd8 = 0, broom = 0, room = 0, winfo = 0;
@@ -202,7 +302,11 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                 if (!ZZ_L2P_WINFO_W) winfo = make_winfo(fwd8, broom, Amask);
             }
             ZZ_T(0);
+#if ZZ_L2P_FLAGS
+            l2p_wait_ge(&S->walked, g, err);                              // the block in front has been walked
+#else
             l2_block_barrier();                                           // Bg (the switch block: Bx) -- the block in front has been walked
+#endif
             ZZ_T(1);
             if (ZZ_L2P_PRIO_W != ZZ_L2P_PRIO_P) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_W);
 
@@ -281,10 +385,16 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                     uint32_t bw = bre < pe ? bre : pe;
                     {
                         const int32_t ce = (int32_t)readlane((uint32_t)c, e);
-                        if (fwd == 16) fwd = l1p_extend_match(TS, qe, ce, ZZ_MAX_LEN, 16);    // remain(), :64-90
                         const uint32_t re = readlane(room, e);
                         const uint32_t blim = re < pe ? re : pe;
+#ifdef ZZ_L2P_X_NOEXT
+                        (void)ce; (void)blim;                            // TIMING EXPERIMENT (valid but WRONG streams): no extension loads
+#elif ZZ_L2P_EXT_BOTH
+                        l2p_extend_both(TS, src, qe, ce, fwd == 16, bw == 8 && blim > 8, blim, fwd, bw);
+#else
+                        if (fwd == 16) fwd = l1p_extend_match(TS, qe, ce, ZZ_MAX_LEN, 16);    // remain(), :64-90
                         if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
+#endif
                     }
                     uint32_t mlen = fwd + bw;
                     if (mlen > ZZ_MAX_LEN) mlen = ZZ_MAX_LEN;                                           // :412-415
@@ -300,8 +410,18 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                 B = base + (uint32_t)Brel;
                 nextProbe = base + np;
                 // the parser behind is waiting for these two and nothing else: out first
+#if ZZ_L2P_FLAGS
+                xb[0] = B; xb[1] = nextProbe;                             // (the same words from all lanes)
+#else
                 if (lane == 0) { xb[0] = B; xb[1] = nextProbe; }
+#endif
             }
+#if ZZ_L2P_FLAGS
+            ZZ_WAVE_SYNC();
+            S->walked = g + 1;                                            // the walk of block g + 1 may start
+            if (ZZ_L2P_PRIO_W != ZZ_L2P_PRIO_P) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);     // what follows runs beside it
+            if (g >= 2) l2p_wait_ge(&S->cons, g - 1, err);                // the helper has taken block g - 2 out of this slot
+#endif
             myNext = nextProbe;
             ZZ_T(2); ZZ_C(11, (uint32_t)__builtin_popcountll(evmask)); ZZ_C(12, (uint32_t)__builtin_popcountll(slowmask));
             // ---- this block's matches: starts and lengths, their symbols, the covered / match-start bits; one word per match
@@ -342,15 +462,22 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
             slot[64] = (uint32_t)evmask; slot[65] = (uint32_t)(evmask >> 32);     // (the same words from all lanes: no lane mask to set up)
             wa = wan; wa2 = wan2; wb = wbn;
             ZZ_T(3);
+#if ZZ_L2P_FLAGS
+            ZZ_WAVE_SYNC();
+            S->tok[g & 1u] = g + 1;                                       // the helper may take this block's match words
+#else
             l2_block_barrier();                                           // B_g+1: this block has been walked
             ZZ_T(4);
             if (ZZ_L2P_PRIO_W != ZZ_L2P_PRIO_P) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
+#endif
         };
         if (g >= 1 && !sw && base + 64 <= batchEnd) block(std::true_type{});
         else block(std::false_type{});
     }
+#if !ZZ_L2P_FLAGS
     if (gs < NB && gs + 1 >= NB && pw == 1) l2_block_barrier();          // Bx, where the switch block is the packet's last
     if (((NB - 1) & 1u) != pw) l2_block_barrier();                       // B_NB: the other parser's last walk (NB = 0: B0)
+#endif
 #ifdef ZZ_PROF
     if (lane == 0 && prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&prof[16 * (1 + pw) + _i], prof_acc[_i]);
 #endif
@@ -361,8 +488,11 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
 // block that can no longer change is turned into records (zz_level2.h, l2_helper_pass: everything else is the walker's now).
 __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
                                                     uint32_t* tokens, uint16_t* recs, const uint8_t* src, uint32_t n,
-                                                    uint32_t& nrec_out, uint32_t& adA, uint64_t& adC, unsigned long long* prof = nullptr)
+                                                    uint32_t& nrec_out, uint32_t& adA, uint64_t& adC, uint32_t* xb, uint32_t* err,
+                                                    unsigned long long* prof = nullptr)
 {
+    l2p_sync* const S = (l2p_sync*)xb;
+    (void)S; (void)err;
     const int lane = lane_id();
     ZZ_PROF_DECL
     const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0;
@@ -371,7 +501,9 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
     uint32_t nrec = 0, Fnext = 0, ntok = 0;
     adA = 0; adC = 0;
     if (ZZ_L2P_PRIO_H) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_H);
+#if !ZZ_L2P_FLAGS
     l2_block_barrier();                                                  // B0
+#endif
     for (uint32_t i = 0; i < trips; ++i) {
         const uint32_t base = i << 6;
         uint32_t fbyte = 0;
@@ -381,12 +513,20 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
             adA += fbyte; adC += (uint64_t)p * fbyte;
         }
         ZZ_T(1); ZZ_C(10, 1);
+#if ZZ_L2P_FLAGS
+        l2p_wait_ge(&S->tok[i & 1u], i + 1, err);                        // block i's match words and bits are in place
+#else
         if (i == gs) l2_block_barrier();                                 // Bx
         l2_block_barrier();                                              // B_i+1: block i has been walked
+#endif
         ZZ_T(0);
         const uint32_t* slot = hb + (i & 1) * ZZ_L2_HB_WORDS;
         const uint32_t tok = slot[lane];
         const uint64_t evmask = ((uint64_t)uniform(slot[65]) << 32) | uniform(slot[64]);
+#if ZZ_L2P_FLAGS
+        ZZ_WAVE_SYNC();
+        S->cons = i + 1;                                                 // the slot is free for block i + 2
+#endif
         if (evmask) {
             if ((evmask >> lane) & 1) {
                 tokens[ntok + mbcnt(evmask)] = tok;
