@@ -1099,6 +1099,12 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
     auto packet = [&](const uint32_t k, auto roletag) {
         constexpr int ROLE = decltype(roletag)::value;       // 0: parser (+ codes, first part of the emission), 1: helper, 2 (PP): second parser
         constexpr bool W0 = ROLE == 0, PB = ROLE == 2;
+        // Behind the token pass: CODER builds the codes and emits the first part of the body, MID the second (PP: PB the third).
+        // Two wavefronts: the parser codes. PP: the HELPER codes and wavefront 0 takes the middle part -- a parser's token pass
+        // wants every register it can get, and with the code construction in the same wavefront the compiler kept 31 packet-invariant
+        // values in scratch and read eight of them back on every out-of-line token of the walk (parser 0's walk 2,541 cycles per
+        // block of the mix against parser 1's 1,793: profiles/r05_phases_l2p_mix_first.txt); the helper's token-pass loop is small.
+        constexpr bool CODER = (PP && ZZ_L2P_HELPER_CODES) ? ROLE == 1 : W0, MID = (PP && ZZ_L2P_HELPER_CODES) ? W0 : ROLE == 1;
         const uint64_t off = (uint64_t)k * P.packet_size;
         const uint32_t len = (uint32_t)((P.n - off) < P.packet_size ? (P.n - off) : P.packet_size);
         const bool is_final = P.last_is_final && k == P.npk - 1;
@@ -1213,11 +1219,11 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             }
             return;
         }
-        if (!W0) {
-            if (n == 0 && P.cks_kind == ZZ_CKS_ADLER) {     // (n > 0: summed during the token pass)
-                zz_cks c = wave_adler(src, len);
-                if (lane == 0) P.cks[k] = c;
-            }
+        if (ROLE == 1 && n == 0 && P.cks_kind == ZZ_CKS_ADLER) {     // (n > 0: summed during the token pass)
+            zz_cks c = wave_adler(src, len);
+            if (lane == 0) P.cks[k] = c;
+        }
+        if (MID) {
             if (n > 0) {
                 __syncthreads();             // (X) codes are ready, or the block went out stored
                 if (uniform(share[0]) == 2) {
@@ -1263,7 +1269,8 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             }
             return;
         }
-        // ---- wavefront 0 alone from here to the end of the packet ------------------------------------------------
+        // ---- the coding wavefront alone from here to the end of the packet ---------------------------------------------
+        if (PP && ZZ_L2P_HELPER_CODES) __builtin_amdgcn_s_setprio(3);      // (the helper's token-pass priority is its own: l2p_helper_pass sets it per packet)
         bitring ring;
         ring_init(ring, ring_words, out);
         if (n > 0) {
@@ -1406,7 +1413,9 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
         __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
         for (uint32_t k = Q.k0 + blockIdx.x; k < Q.k1; k = next_packet()) packet(k, std::integral_constant<int, 2>());
     }
-    ZZ_PROF_FLUSH(P);
+#ifdef ZZ_PROF
+    if (threadIdx.x == ((PP && ZZ_L2P_HELPER_CODES) ? 64u : 0u) && P.prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&P.prof[_i], prof_acc[_i]);     // the coding wavefront's stamps
+#endif
 }
 
 // xdepth: 0 = levels 2,3; 2 / 4 / 8 = the extended levels 4 / 5 / 6 (chain depth)

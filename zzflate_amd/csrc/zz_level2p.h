@@ -54,6 +54,23 @@ namespace zz {
 #ifndef ZZ_L2P_EXT_BOTH
 #define ZZ_L2P_EXT_BOTH 0
 #endif
+// bytes a probe compares forward on the prober's side: 16 (zz_level2.h's quick length) or 32 -- where some lane of a block agrees with its
+// candidate in all sixteen bytes, every lane loads the next sixteen at its position and at its candidate, and only a length of "32 or
+// more" is left to the walk's out-of-line path (a memory round trip on the packet's chain: profiles/r05_family_rates_and_free_extension_probe.txt)
+// ZZ_L2P_FWD32 = k: up to k further rounds of sixteen bytes (0: the quick length as it was; 1: 32 bytes; 2: 48)
+#ifndef ZZ_L2P_FWD32
+#define ZZ_L2P_FWD32 1
+#endif
+#define ZZ_L2P_FCAP (16u + 16u * ZZ_L2P_FWD32)
+#if ZZ_L2P_FWD32 && ZZ_L2P_EXT_BOTH
+#error "l2p_extend_both starts at byte 16: build it with -DZZ_L2P_FWD32=0"
+#endif
+// who builds the codes and emits the first part behind the token pass: 1 = the helper (the parsers' token pass keeps its registers), 0 = wavefront 0
+// (measured, profiles/r05_ab_l2p_roles_and_forward_32_*.txt: with the helper coding the spills of the parsers' out-of-line path go --
+// parser 0's walk on the mix 2,541 -> 1,261 cycles per block -- and level 2 text is 1.1 % slower, the mix the same, log lines +1.2 %: 0)
+#ifndef ZZ_L2P_HELPER_CODES
+#define ZZ_L2P_HELPER_CODES 0
+#endif
 // the body's three parts in 64ths of the records: wavefront 0 takes [0, SPLIT1), the helper [SPLIT1, SPLIT2), the second parser the
 // rest; a dry run over a record costs about 0.4 of emitting it, so equal finishing times want 0.51 / 0.31 / 0.18
 #ifndef ZZ_L2P_SPLIT1
@@ -178,36 +195,19 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
     if (pw == 0 && lane == 0) { xb[0] = 1; xb[1] = 1; }               // backRefEnd (:380), j (:383)
     if (pw == 1) l2_block_barrier();                                  // B0
 #endif
-    for (uint32_t g = pw; g < NB; g += 2) {
-        const uint32_t base = g << 6;
-        const bool sw = g == gs;
-#if !ZZ_L2P_FLAGS
-        if (g == ZZ_L2P_SWITCH_BLOCK + 1 && gs == ZZ_L2P_SWITCH_BLOCK) l2_block_barrier();   // Bx: the switch block's entries are in the table
-#endif
-        uint32_t skipPos = 0xFFFFFFFFu;
-        // blocks behind the switch belong to the second batch, which ends where the search region ends: a packet's rest is shorter
-        // than a batch (s2 >= 16384, target <= 32509); a match that overruns batch AND region leaves nothing to probe (nextProbe > target)
-        const uint32_t batchEnd = g < gs ? batch1 : target;
-        if (sw) {
-            // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first byte is entered only if
-            // the last match covered it. Needs the walk of block g - 1: this block's P runs behind Bg, and Bx follows it.
-#if ZZ_L2P_FLAGS
-            l2p_wait_ge(&S->walked, g, err);
-#else
-            l2_block_barrier();                                       // Bg
-#endif
-            const uint32_t Bw = uniform(xb[0]);
-            const uint32_t s2 = Bw > batch1 ? Bw : batch1;
-            skipPos = Bw >= batch1 ? 0xFFFFFFFFu : batch1;
-            ZZ_WAVE_SYNC();
-            if (lane == 0) { xb[0] = s2 + 1; xb[1] = s2 + 1; }
-            myNext = s2 + 1;
-        }
+    // Loop state the block's code reads: set by whoever calls it. Most blocks are INTERIOR (below); they run in a loop of their own
+    // with nothing between two blocks but the counter (every scalar instruction between two blocks is the prober's: 500 cycles of
+    // loop top per block in the first form, profiles/r05_phases_l2p_text_first.txt). Everything else -- the packet's first blocks,
+    // the switch block and the one behind it, the last ones -- goes through `general`.
+    uint32_t g = pw, base = 0, skipPos = 0xFFFFFFFFu, batchEnd = batch1;
+    bool sw = false;
+    {
         // the walk's word per lane: fwd8 [4:0], need [7:5], "8 or more backward possible" bit 8, "16 or more forward" bit 9, plain bit 10,
         // strong bit 11, next candidate [21:16] (0 = none), lane + fwd8 [29:23] (zz_level2.h, ZZ_L2_HOP)
         auto make_winfo = [&](uint32_t fwd8, uint32_t broom, uint64_t Amask) -> uint32_t {
-            const uint32_t inexact = (fwd8 & 16u) | (broom & 8u);
-            uint32_t winfo = fwd8 | (sub_from4_sat(fwd8) << 5) | (inexact << 5) | (((fwd8 + 28u) & 32u) << 6) |
+            // ("FCAP or more" forward -> bit 9, "8 or more" backward -> bit 8; the scalar loop never reads bits 0..4: no length there)
+            const uint32_t inexact = (fwd8 == ZZ_L2P_FCAP ? 16u : 0u) | (broom & 8u);
+            uint32_t winfo = (sub_from4_sat(fwd8) << 5) | (inexact << 5) | (fwd8 >= 4 ? 0x800u : 0u) |
                              ((fwd8 >= 4 && inexact == 0) ? 0x400u : 0u) | (((uint32_t)lane + fwd8) << 23);
             const uint32_t endl = (uint32_t)lane + fwd8 + 1;                  // first lane probed after a match here
             const uint64_t m = Amask >> (endl & 63u);
@@ -295,6 +295,20 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                     }
                     fwd8 = equal_bits128(wa ^ ca, wa2 ^ ca2, 128u) >> 3;   // 16 = "16 or more" (:399)
                     if (!has) fwd8 = 0;
+#if ZZ_L2P_FWD32
+#pragma unroll
+                    for (uint32_t at = 16u; at < ZZ_L2P_FCAP; at += 16u) {
+                        if (!ballot(fwd8 == at)) break;
+                        // the next sixteen bytes (every lane loads: no lane mask; a lane that is not that far reads its own bytes
+                        // against its own: inside the packet either way, q + 16 + FCAP < n and the candidate lies below q)
+                        const bool go = fwd8 == at;
+                        uint64_t ya, ya2, yc, yc2;
+                        ld128<false>(src + q + (go ? at : 0u), end, ya, ya2);
+                        ld128<false>(src + (go ? c + (int32_t)at : (int32_t)q), end, yc, yc2);
+                        const uint32_t f2 = equal_bits128(ya ^ yc, ya2 ^ yc2, 128u) >> 3;
+                        if (go) fwd8 = at + f2;                           // FCAP = "FCAP or more"
+                    }
+#endif
                 }
                 broom = bwd8 < room ? bwd8 : room;
                 if (!has) broom = 0;
@@ -390,9 +404,9 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
 #ifdef ZZ_L2P_X_NOEXT
                         (void)ce; (void)blim;                            // TIMING EXPERIMENT (valid but WRONG streams): no extension loads
 #elif ZZ_L2P_EXT_BOTH
-                        l2p_extend_both(TS, src, qe, ce, fwd == 16, bw == 8 && blim > 8, blim, fwd, bw);
+                        l2p_extend_both(TS, src, qe, ce, fwd == ZZ_L2P_FCAP, bw == 8 && blim > 8, blim, fwd, bw);
 #else
-                        if (fwd == 16) fwd = l1p_extend_match(TS, qe, ce, ZZ_MAX_LEN, 16);    // remain(), :64-90
+                        if (fwd == ZZ_L2P_FCAP) fwd = l1p_extend_match(TS, qe, ce, ZZ_MAX_LEN, ZZ_L2P_FCAP);    // remain(), :64-90
                         if (bw == 8 && blim > 8) bw = wave_extend_back(src, qe, ce, blim);            // :92-102
 #endif
                     }
@@ -471,8 +485,47 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
             if (ZZ_L2P_PRIO_W != ZZ_L2P_PRIO_P) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
 #endif
         };
-        if (g >= 1 && !sw && base + 64 <= batchEnd) block(std::true_type{});
-        else block(std::false_type{});
+        // the blocks [g, hi) that are INTERIOR (not block 0 or 1, not the switch block or the one behind it, every position inside the batch)
+        auto interior_end = [&](uint32_t g0) -> uint32_t {
+            if (g0 < 2 || g0 == gs || (gs == ZZ_L2P_SWITCH_BLOCK && g0 == ZZ_L2P_SWITCH_BLOCK + 1)) return g0;
+            const uint32_t hi = g0 < gs ? ((batch1 >> 6) < gs ? (batch1 >> 6) : gs) : (target >> 6);
+            return hi < NB ? hi : NB;
+        };
+        while (g < NB) {
+            const uint32_t hi = interior_end(g);
+            if (g < hi) {
+                sw = false; skipPos = 0xFFFFFFFFu; batchEnd = g < gs ? batch1 : target;
+                for (; g < hi; g += 2) { base = g << 6; block(std::true_type{}); }
+                continue;
+            }
+            // ---- general: one block with everything that can be special about it
+            base = g << 6;
+            sw = g == gs;
+#if !ZZ_L2P_FLAGS
+            if (g == ZZ_L2P_SWITCH_BLOCK + 1 && gs == ZZ_L2P_SWITCH_BLOCK) l2_block_barrier();   // Bx: the switch block's entries are in the table
+#endif
+            skipPos = 0xFFFFFFFFu;
+            // blocks behind the switch belong to the second batch, which ends where the search region ends: a packet's rest is shorter
+            // than a batch (s2 >= 16384, target <= 32509); a match that overruns batch AND region leaves nothing to probe (nextProbe > target)
+            batchEnd = g < gs ? batch1 : target;
+            if (sw) {
+                // batch switch (:228-230, :435-438): the next batch starts at max(backRefEnd, end); its first byte is entered only if
+                // the last match covered it. Needs the walk of block g - 1: this block's P runs behind Bg, and Bx follows it.
+#if ZZ_L2P_FLAGS
+                l2p_wait_ge(&S->walked, g, err);
+#else
+                l2_block_barrier();                                       // Bg
+#endif
+                const uint32_t Bw = uniform(xb[0]);
+                const uint32_t s2 = Bw > batch1 ? Bw : batch1;
+                skipPos = Bw >= batch1 ? 0xFFFFFFFFu : batch1;
+                ZZ_WAVE_SYNC();
+                if (lane == 0) { xb[0] = s2 + 1; xb[1] = s2 + 1; }
+                myNext = s2 + 1;
+            }
+            block(std::false_type{});
+            g += 2;
+        }
     }
 #if !ZZ_L2P_FLAGS
     if (gs < NB && gs + 1 >= NB && pw == 1) l2_block_barrier();          // Bx, where the switch block is the packet's last
@@ -500,7 +553,7 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
     const uint32_t gs = l2p_switch_block(target);
     uint32_t nrec = 0, Fnext = 0, ntok = 0;
     adA = 0; adC = 0;
-    if (ZZ_L2P_PRIO_H) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_H);
+    __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_H);                           // (down from the code construction's 3 of the packet before)
 #if !ZZ_L2P_FLAGS
     l2_block_barrier();                                                  // B0
 #endif
@@ -552,7 +605,6 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
         nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, d);
     }
     nrec_out = nrec;
-    if (ZZ_L2P_PRIO_H) __builtin_amdgcn_s_setprio(0);
 #ifdef ZZ_PROF
     if (lane == 0 && prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&prof[48 + _i], prof_acc[_i]);
 #endif
