@@ -66,6 +66,13 @@ namespace zz {
 #ifndef ZZ_L1P_ORDER_CHECK
 #define ZZ_L1P_ORDER_CHECK 0
 #endif
+// the prober compares 32 bytes where the walk has just needed more than 16 (l1p_parse, hot_until). Measured (bit-exact;
+// profiles/r05_ab_l1p_ext32.txt): text +0.4 %, mix -2.3 %, log lines in gzip -9 %, database dump 102 -> 81 GB/s -- at level 1 the
+// prober's interval is as critical as the walker's, and a second memory round trip in it costs more than the one it saves the
+// walk (at level 2, where the prober has slack on such data, the same idea is worth +4 % on the mix and +9 % on log lines). Off.
+#ifndef ZZ_L1P_EXT32
+#define ZZ_L1P_EXT32 0
+#endif
 // the emitter's completed words leave the bit ring in batches of 32..64 (zz_emit.h ring_append_lazy) instead of after every block
 #ifndef ZZ_L1P_LAZY_FLUSH
 #define ZZ_L1P_LAZY_FLUSH 1
@@ -112,6 +119,13 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
     // on k_encode_l1 (zz_api.hip encode_finish).
     uint32_t wmin = ZZ_WAVE;
     uint32_t mycout = 0;                                                  // positions by which this wavefront's last block ran into the next one
+    // ZZ_L1P_EXT32: a match of "16 or more" bytes is extended by the whole wavefront when the walk gets to it -- a dependent memory
+    // round trip on the packet's chain, 0.9 times per block of C source, and what log lines, XML and HTML lose 8-14 % to
+    // (profiles/r05_family_rates_and_free_extension_probe.txt). Where a wavefront has just had such an event (hot_until: its next
+    // blocks), the PROBER's side compares sixteen more bytes at the table candidate as read for the lanes that agree in all sixteen
+    // (`ext`); the walk takes the length from there unless the lane's candidate moved or sits inside the block, and only "32 or more"
+    // still asks memory. One scalar compare per block where the gate is shut (text: nearly always).
+    uint32_t hot_until = 0;
     if (pw == 1) l1_group_barrier();                                      // B_0: block 0 has entered its positions
     uint32_t xlo_next = pw ? 1u + BIAS : 0xFFFF0000u;                     // block 1: base - 63 = 1; block 0: nothing can be a cross lane
     for (uint32_t g = pw; g < NB; g += 2) {
@@ -229,6 +243,20 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 const uint32_t di = ZZ_WI_DUP | (ql << ZZ_WI_QLANE_SHIFT) | (hard ? ZZ_WI_HARD : 0u) | lbf;
                 infoB = dup ? di : 0u;
             }
+            uint32_t ext;                                                // equal bytes 16..31 at the table candidate as read (16: all of them); see hot_until
+            asm volatile("" : "=v"(ext));
+            const bool gate = ZZ_L1P_EXT32 && BIAS == 0 && INT && g < hot_until;
+            if (gate) {
+                const bool all16 = ((w ^ wc) | (w2 ^ wc2)) == 0 && oldraw != 0;
+                if (ballot(all16)) {
+                    // (every lane loads: no lane mask; a lane that does not agree reads its own bytes against its own. Interior
+                    // block: p + 32 <= n, and the candidate lies below p)
+                    uint64_t ya, ya2, yc, yc2;
+                    l1p_ld128u<false>(SRC, p + (all16 ? 16u : 0u), ya, ya2);
+                    l1p_ld128u<false>(SRC, all16 ? oldraw + 15u : p, yc, yc2);           // (entry - 1 + 16)
+                    ext = equal_bits128(ya ^ yc, ya2 ^ yc2, 128u) >> 3;
+                }
+            }
             ZZ_T(0);
             l1_group_barrier();                                          // B_g: block g - 1 has been walked
             if (ZZ_L1P_PRIO_W != ZZ_L1P_PRIO_F) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_W);
@@ -240,6 +268,7 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
             uint32_t cin;
             uint32_t told, info;
             uint64_t x;                                                  // the candidate's first eight bytes XOR mine
+            uint64_t MV;                                                 // lanes whose candidate is not the entry they read
             {
                 // Everything between the barrier and the walk is on the packet's critical path, instruction by instruction. Both
                 // reads go out at once and unconditionally: a lane that is not a cross lane reads the sentinel (win[65] = 65 = its
@@ -256,7 +285,8 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                 ZZ_T(7);                                                   // (diagnostic builds: the two LDS reads have come back)
                 // the block behind is waiting for this (its cross lanes' second candidate): out first
                 X->told[lane] = told | tag;
-                const uint64_t LDM = ballot(moved) & ~ballot(use3);
+                MV = ballot(moved);
+                const uint64_t LDM = MV & ~ballot(use3);
                 // (interior blocks: the cap IS "16 | the flag", see LENB above: three instructions less between the barrier and the walk)
                 constexpr uint32_t CAPA = (ZZ_WI_CAP | ZZ_WI_EXTA) << 3;
                 auto compare = [&]() {
@@ -333,7 +363,12 @@ __device__ __forceinline__ void l1p_parse(const zz_packet_params& P, const l1_pk
                             (void)cand;                                  // TIMING EXPERIMENT (valid but WRONG streams): "16 or more" is 16, no extension loads
                             mlen = maxlen < ZZ_WI_CAP ? maxlen : ZZ_WI_CAP;
 #else
-                            mlen = l1p_extend_match(SRC, pe, cand, maxlen, ZZ_WI_CAP);
+                            // (the prober's sixteen further bytes hold for the entry as this lane read it: not for a candidate inside
+                            // the block, not where the walk of the block in front moved it)
+                            const uint32_t e16 = (gate && !useB && !((MV >> e) & 1)) ? readlane(ext, e) : 0xFFu;
+                            if (e16 < 16u) mlen = 16u + e16;             // (an interior block: 32 bytes lie inside the packet)
+                            else mlen = l1p_extend_match(SRC, pe, cand, maxlen, e16 == 16u ? 32u : ZZ_WI_CAP);
+                            if (ZZ_L1P_EXT32) hot_until = g + 8u;
 #endif
                             if (lane == e) ovlen = mlen | 0x8000u;
                             ovmL |= 1ull << e;
