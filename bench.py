@@ -140,7 +140,7 @@ def summarize_regions(times, steps):
 
 def want_another_region(times, min_total=1.0, max_repeats=64):
     """keep timing regions until they add up to a second (at least one, at most 64)"""
-    return len(times) < max_repeats and sum(times) < min_total
+    return not times or (len(times) < max_repeats and sum(times) < min_total)
 
 
 def scalar_bound(scalar_insts, kernel_ms, cus=256, clock_ghz=2.4):

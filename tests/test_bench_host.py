@@ -78,6 +78,7 @@ def test_timed_regions_are_repeated_to_a_second_and_summarised_by_their_median()
     assert len(times) == 7 and sum(times) >= 1.0
     assert not bench.want_another_region([1.2]) and bench.want_another_region([])
     assert not bench.want_another_region([0.001] * 64)           # bounded
+    assert bench.want_another_region([], 0.0) and not bench.want_another_region([0.01], 0.0)     # --min-seconds 0: exactly one region
     r = bench.summarize_regions([0.160, 0.150, 0.155, 0.152, 0.300], 20)
     assert r["repeats"] == 5 and abs(r["ms_per_step"] - 7.75) < 1e-9
     assert abs(r["ms_per_step_min"] - 7.5) < 1e-9 and abs(r["ms_per_step_max"] - 15.0) < 1e-9
