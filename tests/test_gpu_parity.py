@@ -628,6 +628,19 @@ def test_lds_order_violation_seen_by_the_kernel_reruns_the_call(gpu, oracle, cor
         ctx.encode_async(src, len(d), dst, cap, 1, 1, 32768)
         w = ctx.finish()
         assert dst[:w].cpu().numpy().tobytes() == want and zz.lib.zz_debug_lds_order_verdict(0) == 0
+        # levels 2,3: k_encode_l2p enters a block's positions by one ordered LDS exchange per lane and checks what comes back; a
+        # violation reruns the call on the two-wavefront kernel, which reads, writes, reads back and ranks same-hash lanes itself
+        zz.lib.zz_debug_reset_lds_order(0)
+        assert zz.lib.zz_debug_lds_order_verdict(0) == 1 and zz.lib.zz_debug_l2_kernel(ctx._h) == 2     # (asking for the verdict runs the probe again)
+        for lvl in (2, 3):
+            want2 = oracle.encode_packets(d, 0, lvl, 32768)
+            zz.lib.zz_debug_reset_lds_order(0)
+            assert zz.lib.zz_debug_lds_order_verdict(0) == 1
+            assert enc(lvl) == want2
+            zz.lib.zz_debug_force_lds_violation(1)
+            assert enc(lvl) == want2                           # reported by the kernel, run again, same bytes
+            assert zz.lib.zz_debug_lds_order_verdict(0) == 0 and zz.lib.zz_debug_l2_kernel(ctx._h) == 1
+            assert enc(lvl) == want2                           # and from here on the two-wavefront kernel straight away
         # warm window, levels 1 and 2: no other form exists, the call fails loudly
         for lvl in (1, 2):
             zz.lib.zz_debug_reset_lds_order(0)

@@ -105,9 +105,10 @@ def _load():
         "zz_debug_force_lds_violation": (None, [i32]),
         "zz_debug_reset_lds_order": (None, [i32]),
         "zz_debug_l1_kernel": (i32, [vp]),
+        "zz_debug_l2_kernel": (i32, [vp]),
     }
     # (diagnostic hooks an older experimental build named by ZZFLATE_AMD_LIB may lack: A/B runs of tools/abn.sh)
-    optional = {"zz_build_flags", "zz_debug_force_lds_violation", "zz_debug_reset_lds_order", "zz_debug_l1_kernel"}
+    optional = {"zz_build_flags", "zz_debug_force_lds_violation", "zz_debug_reset_lds_order", "zz_debug_l1_kernel", "zz_debug_l2_kernel"}
     for name, (res, args) in sig.items():
         if name in optional and not hasattr(L, name):
             continue

@@ -59,6 +59,9 @@ extern "C" const char* zz_build_flags(void)
 #if ZZ_L2P_FLAGS
         " ZZ_L2P_FLAGS"
 #endif
+#if !ZZ_L2P_XCHG
+        " ZZ_L2P_XCHG=0"
+#endif
 #ifdef ZZ_PROF
         " ZZ_PROF"
 #endif
@@ -495,9 +498,17 @@ static bool l1_classic()
     static const bool classic = [] { const char* e = getenv("ZZFLATE_L1_KERNEL"); return e && !strcmp(e, "classic"); }();
     return classic;
 }
+// ZZFLATE_L2_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet at levels 2,3 instead of two; the streams are the same
+static bool l2_classic()
+{
+    static const bool classic = [] { const char* e = getenv("ZZFLATE_L2_KERNEL"); return e && !strcmp(e, "classic"); }();
+    return classic;
+}
 // (not part of the public header) which level-1 kernel a cold packet-mode call on this context would launch now: 2 = k_encode_l1p
 // (two parsing wavefronts), 1 = k_encode_l1 (ZZFLATE_L1_KERNEL=classic, or the device's LDS-order verdict is negative)
 extern "C" int zz_debug_l1_kernel(const zz_ctx* c) { return (c && !l1_classic() && lds_order_cached(c->device)) ? 2 : 1; }
+// (the same for levels 2,3: 2 = k_encode_l2p, 1 = the two-wavefront k_encode_l2_t<0, false>)
+extern "C" int zz_debug_l2_kernel(const zz_ctx* c) { return (c && !l2_classic() && (!ZZ_L2P_XCHG || lds_order_cached(c->device))) ? 2 : 1; }
 // The common pipeline. with_container: write header/trailer (whole stream) or not (shard).
 static int encode_finish(zz_ctx* c, zz_result* host_res);
 // `host_res` == nullptr: enqueue only (zz_encode_device_async); the caller collects with encode_finish.
@@ -557,7 +568,9 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
         pp.dbg_viol = 0;
         // does this launch rely on the LDS's lane order (and check it as it goes: error bit 4)? k_encode_l1p; the warm window's pre-hash
         const bool l1p = level == 1 && !warm && !one_parser && !l1_classic() && lds_order_cached(c->device);
-        order_checked = l1p || (warm != 0 && xdepth == 0);
+        // ... and k_encode_l2p (levels 2,3, cold): its insert is an ordered exchange (zz_level2p.h, ZZ_L2P_XCHG)
+        const bool l2p = level >= 2 && !warm && xdepth == 0 && !one_parser && !l2_classic() && (!ZZ_L2P_XCHG || lds_order_cached(c->device));
+        order_checked = l1p || (warm != 0 && xdepth == 0) || (l2p && ZZ_L2P_XCHG);
         if (order_checked) {
             int left = g_force_violation.load();
             while (left > 0 && !g_force_violation.compare_exchange_weak(left, left - 1)) {}
@@ -593,7 +606,7 @@ static int encode_common(zz_ctx* c, const uint8_t* d_src, uint64_t n, uint64_t h
             else hipLaunchKernelGGL(k_encode_l1p, dim3(npk), dim3(ZZ_L1P_THREADS), pad_lds, st, pp);
         } else {
             hipLaunchKernelGGL(k_fill_tail, dim3(1), dim3(128), 0, st, pp.src, pp.n, c->d_tail);
-            launch_level2(pp, c->l2_scratch, c->d_work, st, xdepth);
+            launch_level2(pp, c->l2_scratch, c->d_work, st, xdepth, l2p);
         }
         if (c->timing) { HIPCHK(hipEventRecord(c->ev1, st)); c->have_time = true; }
         if (level != 0) {
@@ -633,9 +646,9 @@ static int encode_finish(zz_ctx* c, zz_result* host_res)
     *host_res = *c->h_res;
     if (c->h_err[0] & 4u) {
         // A kernel of this call saw the LDS leave a LOWER lane's store in a slot that a higher lane of the same instruction wrote too
-        // (zz_level1p.h P2; zz_level1.h warm_prehash): what it wrote is a valid stream, but not necessarily the reference's. The
-        // device loses its verdict; level 1 runs the CALL again on the one-wavefront kernel, which asks the LDS for nothing of the
-        // kind (same bytes as k_encode_l1p where that one is right); a warm window has no such form and is refused from here on.
+        // (zz_level1p.h P2; zz_level1.h warm_prehash; zz_level2p.h's exchange): what it wrote is a valid stream, but not necessarily
+        // the reference's. The device loses its verdict; levels 1..3 run the CALL again on the one-parser kernels, which ask the LDS
+        // for nothing of the kind (same bytes where the two-parser ones are right); a warm window has no such form and is refused.
         lds_order_revoke(c->device);
         if (!c->pend.order_checked) { set_err("internal: LDS-order violation reported by a kernel that does not check it"); return ZZ_E_HIP; }
         if (c->pend.warm) {

@@ -1143,10 +1143,10 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                 // two parsers: B0 also says "the table is clear" to the second one, "window and counters are" to both
                 if (W0) {
                     if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_P);
-                    l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 0u, P.err, P.prof);
+                    l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 0u, P.err, P.dbg_viol, P.prof);
                     if (ZZ_L2P_PRIO_P != 3) __builtin_amdgcn_s_setprio(3);
                 }
-                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 1u, P.err, P.prof);
+                if (PB) l2p_token_pass(T, hb, xb, covw, mstw, histP, src, end, l1p_make_src(P, src, end), n, before, 1u, P.err, P.dbg_viol, P.prof);
             } else if (W0) {
                 if (BIAS) {
                     // warm window: every position of the last P.warm bytes in front of the packet under the hash of its
@@ -1444,16 +1444,16 @@ static inline uint64_t l2_scratch_bytes(uint32_t npk, int xdepth, uint32_t P)
     if (xdepth) need += l6_m_bytes(npk, P) + (uint64_t)l6_match_grid() * 32768u * 2u * (uint32_t)xdepth;   // + the chains of every resident packet
     return need;
 }
-static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st, int xdepth = 0)
+// two_parser: levels 2,3 with cold packets on k_encode_l2p (the caller decides: not behind ZZFLATE_L2_KERNEL=classic, and -- its insert
+// is an ordered LDS exchange -- only where the device's LDS-order verdict is positive)
+static inline void launch_level2(const zz_packet_params& pp, uint8_t* scratch, uint32_t* work, hipStream_t st, int xdepth = 0, bool two_parser = true)
 {
     zz_l2_params q; q.pk = pp; q.scratch = scratch; q.work = work; q.m = nullptr; q.k0 = 0; q.k1 = pp.npk;
     if (!xdepth) {
         (void)hipMemsetAsync(work, 0, sizeof(uint32_t), st);
         const dim3 g(l2_grid(pp.npk)), b(ZZ_L2_THREADS);
-        // ZZFLATE_L2_KERNEL=classic (diagnostic, A/B): one parsing wavefront per packet instead of two; the streams are the same
-        static const bool classic = [] { const char* e = getenv("ZZFLATE_L2_KERNEL"); return e && !strcmp(e, "classic"); }();
         if (pp.warm) hipLaunchKernelGGL((k_encode_l2_t<32768u, false>), g, b, 0, st, q);
-        else if (classic) hipLaunchKernelGGL((k_encode_l2_t<0u, false>), g, b, 0, st, q);
+        else if (!two_parser) hipLaunchKernelGGL((k_encode_l2_t<0u, false>), g, b, 0, st, q);
         else hipLaunchKernelGGL((k_encode_l2_t<0u, false, true>), dim3(l2_grid(pp.npk, false, ZZ_L2P_WPE >= 7 ? 9 : 8)), dim3(ZZ_L2P_THREADS), 0, st, q);
         return;
     }

@@ -71,6 +71,18 @@ namespace zz {
 #ifndef ZZ_L2P_HELPER_CODES
 #define ZZ_L2P_HELPER_CODES 0
 #endif
+// How a block's positions get into the table: 0 = read / write / read-back, six-ballot same-hash sets, the last member rewrites the
+// slot, in-block candidates' bytes through ds_bpermute (zz_level2.h's way: asks the LDS for nothing undocumented); 1 = ONE ordered
+// exchange per lane (ds_mskor_rtn_b32 on the word that holds the 16-bit slot): the LDS serves the lanes of one instruction that hit
+// one address in ascending lane order, so what a lane gets back IS its candidate -- the table's entry, or the nearest lower lane of
+// the block with its hash -- and the slot ends up with the last one; no read-back, no sets, no rewrite, and a candidate inside the
+// block is loaded like any other (its bytes are in the cache). About 65 of the prober's 170 instructions per block. The property is
+// the one level 1's kernel stands on: probed per device (k_lds_order_probe checks this very instruction), checked here in the blocks
+// at a packet's edges (what comes back must lie below the lane's own position), ZZ_ERR_LDS_ORDER reruns the call on the
+// two-wavefront kernel.
+#ifndef ZZ_L2P_XCHG
+#define ZZ_L2P_XCHG 1
+#endif
 // the body's three parts in 64ths of the records: wavefront 0 takes [0, SPLIT1), the helper [SPLIT1, SPLIT2), the second parser the
 // rest; a dry run over a record costs about 0.4 of emitting it, so equal finishing times want 0.51 / 0.31 / 0.18
 #ifndef ZZ_L2P_SPLIT1
@@ -167,7 +179,7 @@ __device__ __forceinline__ void l2p_extend_both(const l1p_src& TS, const uint8_t
 // of the block walked last left them. Barriers: see above; every wavefront of the workgroup executes B0 .. B_NB (+ Bx).
 __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32_t* xb, uint64_t* covw, uint64_t* mstw, uint32_t* histP, const uint8_t* src,
                                                const uint8_t* end, const l1p_src& TS, const uint32_t n, const uint64_t before, const uint32_t pw,
-                                               uint32_t* err, unsigned long long* prof = nullptr)
+                                               uint32_t* err, const uint32_t dbg_viol, unsigned long long* prof = nullptr)
 {
     l2p_sync* const S = (l2p_sync*)xb;     // (xb[0], xb[1] are S->B, S->nextProbe)
     (void)S; (void)err;
@@ -191,6 +203,7 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
         }
     }
     uint32_t myNext = 1;            // the next probe position as this wavefront knew it last: a lower bound of the true one
+    uint32_t viol = 0;              // ZZ_L2P_XCHG: the exchange handed a lane something that is not below its own position
 #if !ZZ_L2P_FLAGS
     if (pw == 0 && lane == 0) { xb[0] = 1; xb[1] = 1; }               // backRefEnd (:380), j (:383)
     if (pw == 1) l2_block_barrier();                                  // B0
@@ -227,6 +240,34 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
             const bool cmp = myNext < base + 64;
             const uint32_t h = calc_hash3((uint32_t)wa);                  // CalcHash(source + j), :388
             const uint32_t hs = ins ? h : (uint32_t)(ZZ_L2_LDS_BYTES / 2);
+#if ZZ_L2P_XCHG
+            // this wavefront's next block (g + 2): its own bytes, in flight during the rest of this one (inside the packet: q + 143 < n)
+            uint64_t wan, wan2, wbn;
+            ld128<false>(src + q + 2 * ZZ_WAVE, end, wan, wan2);
+            wbn = load64(src + q + 2 * ZZ_WAVE - 8);
+            uint32_t old;                                                 // :389-390 in one: what the slot held when this lane's turn came
+            {
+                const uint32_t baddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)(T + hs);
+                const uint32_t sh = (baddr & 2u) << 3;
+                uint32_t ret;
+                asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(ret) : "v"(baddr & ~3u), "v"(0xFFFFu << sh), "v"((q + 1) << sh) : "memory");
+                old = (ret >> sh) & 0xFFFFu;
+            }
+            if (!INTERIOR && ins && old > q) viol = 1u;                   // (an entry is a position + 1 below mine: anything else came out of order)
+            if (!ins) old = 0;
+            uint64_t ca = 0, ca2 = 0, cpre = 0;
+            if (cmp) {
+                const uint32_t c0 = __builtin_elementwise_sub_sat(old, 1u);
+                ld128<false>(src + c0, end, ca, ca2);
+                cpre = load64(srcm8 + (c0 > lo8 ? c0 : lo8));          // (too close to the stream's start: fixed up below)
+            }
+            const uint32_t cand1 = old;                                   // candidate as pos+1, 0 = none
+            const uint64_t lost = 0;
+            const bool inl = false;
+            const uint32_t il = 0;
+            (void)lost; (void)inl; (void)il; (void)below_me; (void)above_me;
+#else
             uint32_t old = T[hs];                                         // :389
             T[hs] = (uint16_t)(q + 1);                                    // :390 / :474-480
             if (!ins) old = 0;
@@ -263,6 +304,7 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
                                  : "memory", "scc");
                 } else if (ins && W != (uint32_t)lane && (set & above_me) == 0) T[h] = (uint16_t)(q + 1);
             }
+#endif
             ZZ_WAVE_SYNC();
 #if ZZ_L2P_FLAGS
             S->entered = g + 1;                                           // (behind the stores above: the LDS takes a wavefront's instructions in order)
@@ -531,6 +573,7 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
     if (gs < NB && gs + 1 >= NB && pw == 1) l2_block_barrier();          // Bx, where the switch block is the packet's last
     if (((NB - 1) & 1u) != pw) l2_block_barrier();                       // B_NB: the other parser's last walk (NB = 0: B0)
 #endif
+    if (ZZ_L2P_XCHG && (viol | dbg_viol)) atomicOr(err, ZZ_ERR_LDS_ORDER);             // (per lane, no ballot: rare, and this kernel has no scalar register to spare)
 #ifdef ZZ_PROF
     if (lane == 0 && prof) for (int _i = 0; _i < 16; ++_i) atomicAdd(&prof[16 * (1 + pw) + _i], prof_acc[_i]);
 #endif
