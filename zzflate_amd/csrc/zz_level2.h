@@ -1187,6 +1187,16 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             // the end of the block and the end of the packet. A part's place in the bit stream follows from a dry run over the records
             // in front of it; the words two parts share are put together here at the end.
             if (n > 0) {
+                if (ZZ_L2P_DIST_ON_PB && !ZZ_L2P_HELPER_CODES) {
+                    // the distance code's lengths (30 symbols) beside wavefront 0's literal / length code (286): the heap replay is one lane's
+                    // chain of LDS round trips either way, and this wavefront has nothing else to do until the codes are there
+                    __syncthreads();         // (D1) the counts are unpacked
+                    huff_scratch S2;
+                    S2.rec_freq = (uint32_t*)(lds + 12800); S2.rec_id = nullptr; S2.t_freq = nullptr;
+                    S2.t_left = (uint16_t*)(lds + 12928); S2.t_right = nullptr; S2.t_bits = (uint8_t*)(lds + 13184);
+                    calc_lengths_w(S2, distF, 30, 15, lens + 288);
+                    __syncthreads();         // (D2) the distance lengths are in place
+                }
                 __syncthreads();             // (X) codes are ready, or the block went out stored
                 if (uniform(share[0]) == 2) {
                     const uint32_t nbody = (uint32_t)covw[0], r2 = uniform(share[5]);
@@ -1225,6 +1235,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
         }
         if (MID) {
             if (n > 0) {
+                if (PP && ZZ_L2P_DIST_ON_PB && !ZZ_L2P_HELPER_CODES) { __syncthreads(); __syncthreads(); }      // (D1), (D2)
                 __syncthreads();             // (X) codes are ready, or the block went out stored
                 if (uniform(share[0]) == 2) {
                     // ... then the second part of the records, the end of the block and the end of the packet. Its
@@ -1289,6 +1300,8 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
 
             ZZ_T(2);
             // ================= code construction =================================================================
+            constexpr bool DIST_PB = PP && ZZ_L2P_DIST_ON_PB && !ZZ_L2P_HELPER_CODES;     // the second parser builds the distance code's lengths meanwhile
+            if (DIST_PB) __syncthreads();                                         // (D1) the counts are unpacked
             if (lane == 0) symF[256] += 1;                                       // :470
             ZZ_WAVE_SYNC();
             if (XD) pm_lengths_w(PM, symF, 286, 15, lens); else calc_lengths_w(S, symF, 286, 15, lens);   // ComputeCodes, :171-176
@@ -1297,7 +1310,8 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                 const uint32_t eb = i < 265 || i == 285 ? 0 : (uint32_t)(i - 261) >> 2;
                 bitsum += symF[i] * (lens[i] + eb);
             }
-            if (XD) pm_lengths_w(PM, distF, 30, 15, lens + 288); else calc_lengths_w(S, distF, 30, 15, lens + 288);
+            if (DIST_PB) __syncthreads();                                         // (D2) the distance lengths are in place
+            else if (XD) pm_lengths_w(PM, distF, 30, 15, lens + 288); else calc_lengths_w(S, distF, 30, 15, lens + 288);
             if (lane < 30) {
                 const uint32_t eb = lane < 4 ? 0 : (uint32_t)(lane - 2) >> 1;
                 bitsum += distF[lane] * (lens[288 + lane] + eb);

@@ -83,6 +83,10 @@ namespace zz {
 #ifndef ZZ_L2P_XCHG
 #define ZZ_L2P_XCHG 1
 #endif
+// the distance code's lengths built by the second parser beside wavefront 0's literal / length code (it idles there otherwise)
+#ifndef ZZ_L2P_DIST_ON_PB
+#define ZZ_L2P_DIST_ON_PB 1
+#endif
 // the body's three parts in 64ths of the records: wavefront 0 takes [0, SPLIT1), the helper [SPLIT1, SPLIT2), the second parser the
 // rest; a dry run over a record costs about 0.4 of emitting it, so equal finishing times want 0.51 / 0.31 / 0.18
 #ifndef ZZ_L2P_SPLIT1
