@@ -4,7 +4,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-lib = os.path.join(ROOT, "abl", "prof.so")            # built in the build container (tools/mkab.sh prof -DZZ_PROF) ...
+lib = os.environ.get("ZZ_PROF_LIB") or os.path.join(ROOT, "abl", "prof.so")            # built in the build container (tools/mkab.sh prof -DZZ_PROF) ...
 if not os.path.exists(lib):                            # ... or here
     lib = os.path.join(ROOT, "gpurun_out", "libzz_prof.so")
     os.makedirs(os.path.dirname(lib), exist_ok=True)
@@ -52,12 +52,15 @@ if level in (2, 3) and sets[16 + 10]:
     e = list(sets[48:64]); be = max(1, e[10])
     print(f"helper: blocks {e[10]}; per block: asleep in the barrier {e[0] / be:.0f} cyc, busy {e[1] / be:.0f} cyc")
 if level >= 2:
-    names = ["init+adler", "token pass", "counter unpack", "huffman", "codes", "emit"]
-    tot = sum(prof[:6])
+    names = ["init+adler", "token pass", "counter unpack", "huffman" if not (prof[6] and not prof[9]) else "huffman (what the parts below leave)", "codes", "emit"]
+    tot = sum(prof[:6]) + (sum(prof[6:9]) if prof[6] and not prof[9] else 0)
     print(f"level {level} input {mib} MiB kind {kind}: ratio {out.value / n:.4f}; packets {prof[10]}, tokens/packet {prof[11] / max(1, prof[10]):.0f}, cycles/packet {tot / max(1, prof[10]):.0f} = {tot / max(1, prof[10]) / 32768:.1f} cyc/byte")
     for i, nm in enumerate(names):
         print(f"  {nm:18s} {100.0 * prof[i] / tot:6.2f} %   {prof[i] / max(1, prof[10]):10.0f} cyc/packet")
     pk = max(1, prof[10])
+    if prof[6] and not prof[9]:     # the code construction in parts (stamps 6, 7, 8 inside it; the rest is under "huffman")
+        print("  code construction (cycles/packet): literal / length code's lengths %.0f | distance code's (or the wait for them) %.0f | run lengths %.0f | code-length code + bit count %.0f" % (
+            prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[3] / pk))
     if level >= 4:
         print("  k_l6_matches (cycles/packet, wavefront 0): zero %.0f | histogram %.0f | scan %.0f | rounds before the packet's own blocks %.0f | rounds with chain copies %.0f | window and packet into LDS %.0f | compares %.0f | between packets %.0f" % (
             prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[15] / pk, prof[14] / pk, prof[13] / pk))

@@ -471,6 +471,59 @@ __device__ inline int rle_lengths(const uint8_t* lengths, int n, uint16_t* recs,
     return rle_add(recs, nv, metaF, cur, count);
 }
 
+// The same for all lanes, a lane per run of equal lengths: what a run of c lengths v becomes is a closed form of AddRecords'
+// loops (:191-216) -- v == 0: c = 138 q + r gives q records (18, 138), then (17 or 18, r) if r >= 3, else r plain zeros; v != 0: the
+// length itself, then c - 1 = 6 q + r gives q records (16, 6), then (16, r) if r >= 3, else r times the length again -- so a run
+// knows how many records it writes, a prefix sum over the runs places them, and the meta frequencies take one atomic per kind.
+#ifndef ZZ_L2_RLE_W
+#define ZZ_L2_RLE_W 1
+#endif
+template <int N>
+__device__ __forceinline__ int rle_lengths_w(const uint8_t* lengths, uint16_t* recs, int nv, uint32_t* metaF)
+{
+    constexpr int K = (N + 63) / 64;
+    const int lane = lane_id();
+    uint32_t base = (uint32_t)nv;
+    uint32_t carry = 0;                                      // where the run that reaches into this block of 64 began
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = 64u * k + (uint32_t)lane;
+        const bool in = i < (uint32_t)N;
+        const uint32_t val = in ? lengths[i] : 0xFFu;
+        const uint32_t pv = (in && i > 0) ? lengths[i - 1] : 0xFFu;
+        const uint32_t nx = i + 1 < (uint32_t)N ? lengths[i + 1] : 0xFFu;
+        const uint64_t stm = ballot(in && val != pv);        // runs that begin here
+        const uint64_t below = stm & ((2ull << lane) - 1ull);
+        const uint32_t first = below ? 64u * k + 63u - (uint32_t)__builtin_clzll(below) : carry;
+        const bool e = in && val != nx;                      // the lane at a run's last position writes the run
+        const uint32_t c = e ? i + 1u - first : 1u;
+        const uint32_t q = val == 0 ? c / 138u : (c - 1u) / 6u;
+        const uint32_t r = val == 0 ? c - 138u * q : (c - 1u) - 6u * q;
+        const uint32_t cnt = e ? (val != 0 ? 1u : 0u) + q + (r >= 3u ? 1u : r) : 0u;
+        const uint32_t incl = wave_scan_incl(cnt);
+        if (e) {
+            uint16_t* o = recs + base + (incl - cnt);
+            if (val == 0) {
+                for (uint32_t j = 0; j < q; ++j) *o++ = (uint16_t)(18u | (138u << 8));
+                if (q) atomicAdd(&metaF[18], q);
+                if (r >= 3u) { const uint32_t sym = r < 11u ? 17u : 18u; *o++ = (uint16_t)(sym | (r << 8)); atomicAdd(&metaF[sym], 1u); }
+                else { for (uint32_t j = 0; j < r; ++j) *o++ = 0; if (r) atomicAdd(&metaF[0], r); }
+            } else {
+                *o++ = (uint16_t)val;
+                for (uint32_t j = 0; j < q; ++j) *o++ = (uint16_t)(16u | (6u << 8));
+                if (r >= 3u) *o++ = (uint16_t)(16u | (r << 8));
+                else for (uint32_t j = 0; j < r; ++j) *o++ = (uint16_t)val;
+                atomicAdd(&metaF[val], 1u + (r >= 3u ? 0u : r));
+                if (q + (r >= 3u ? 1u : 0u)) atomicAdd(&metaF[16], q + (r >= 3u ? 1u : 0u));
+            }
+        }
+        base += readlane(incl, 63);
+        if (stm) carry = 64u * k + 63u - (uint32_t)__builtin_clzll(stm);
+    }
+    ZZ_WAVE_SYNC();
+    return (int)base;
+}
+
 // backward twin of wave_extend_match: number of equal bytes going down from src[a-1] / src[b-1], at most
 // maxlen (> 8; the first 8 are known equal). 4 bytes per lane.
 __device__ __forceinline__ uint32_t wave_extend_back(const uint8_t* src, int64_t a, int64_t b, uint32_t maxlen)
@@ -1305,6 +1358,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             if (lane == 0) symF[256] += 1;                                       // :470
             ZZ_WAVE_SYNC();
             if (XD) pm_lengths_w(PM, symF, 286, 15, lens); else calc_lengths_w(S, symF, 286, 15, lens);   // ComputeCodes, :171-176
+            ZZ_T(6);
             uint32_t bitsum = 0;
             for (int i = lane; i < 286; i += ZZ_WAVE) {                          // CountBits, :178-187
                 const uint32_t eb = i < 265 || i == 285 ? 0 : (uint32_t)(i - 261) >> 2;
@@ -1316,12 +1370,23 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                 const uint32_t eb = lane < 4 ? 0 : (uint32_t)(lane - 2) >> 1;
                 bitsum += distF[lane] * (lens[288 + lane] + eb);
             }
+            ZZ_T(7);
+#if ZZ_L2_RLE_W
+            {
+                ZZ_WAVE_SYNC();
+                const int nr = rle_lengths_w<286>(lens, rle, 0, metaF);
+                const int nr2 = rle_lengths_w<30>(lens + 288, rle, nr, metaF);
+                if (lane == 0) { misc[1] = (uint32_t)nr; misc[2] = (uint32_t)nr2; }
+            }
+#else
             if (lane == 0) {
                 int nr = rle_lengths(lens, 286, rle, 0, metaF);
                 misc[1] = (uint32_t)nr;
                 misc[2] = (uint32_t)rle_lengths(lens + 288, 30, rle, nr, metaF);
             }
+#endif
             ZZ_WAVE_SYNC();
+            ZZ_T(8);
             if (XD) pm_lengths_w(PM, metaF, 19, 7, metaLens); else calc_lengths_w(S, metaF, 19, 7, metaLens);   // :263-265
             const uint32_t nrec = misc[2];
             for (uint32_t i = lane; i < nrec; i += ZZ_WAVE) {                    // WriteLengths<LengthCounter>, :20-46
