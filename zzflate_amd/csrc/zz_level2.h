@@ -311,14 +311,35 @@ __device__ inline int calculate_tree_w(huff_scratch& S, const uint32_t* freqs, i
     }
     ZZ_WAVE_SYNC();
     int nt = n;
+#ifndef ZZ_L2_MAKE_HEAP_W
+#define ZZ_L2_MAKE_HEAP_W 1
+#endif
+#if ZZ_L2_MAKE_HEAP_W
+    // make_heap (stl_heap.h:339-360) sifts the parents down one after the other, last parent first. A sift stays inside its parent's
+    // subtree, the parents of one level of the heap have disjoint subtrees, and every deeper level's parents (higher indices) come
+    // before: level by level, deepest first, a lane per parent is the same sequence of moves.
+    if (nrec >= 2) {
+        const int nr = (int)nrec, last = (nr - 2) / 2;
+        for (int L = 31 - __builtin_clz((uint32_t)last + 1u); L >= 0; --L) {
+            const int first = (1 << L) - 1, end = last < (2 << L) - 2 ? last : (2 << L) - 2;
+            for (int p0 = first; p0 <= end; p0 += ZZ_WAVE) {
+                const int p = p0 + lane;
+                if (p <= end) hkey_adjust(hk, p, nr, hk[p]);
+            }
+            ZZ_WAVE_SYNC();
+        }
+    }
+#endif
     if (lane == 0) {
         int nr = (int)nrec;
+#if !ZZ_L2_MAKE_HEAP_W
         if (nr >= 2) {                         // make_heap (stl_heap.h:339-360)
             for (int parent = (nr - 2) / 2;; --parent) {
                 hkey_adjust(hk, parent, nr, hk[parent]);
                 if (parent == 0) break;
             }
         }
+#endif
         while (nr >= 2) {                      // :92-104, pop_heap x2 (stl_heap.h:253-265) + push_heap
             const uint32_t a = hk[0];
             nr--;
