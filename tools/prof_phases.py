@@ -65,7 +65,7 @@ if level >= 2:
         print("  k_l6_matches (cycles/packet, wavefront 0): zero %.0f | histogram %.0f | scan %.0f | rounds before the packet's own blocks %.0f | rounds with chain copies %.0f | window and packet into LDS %.0f | compares %.0f | between packets %.0f" % (
             prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[15] / pk, prof[14] / pk, prof[13] / pk))
         sys.exit(0)
-    print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f | finish block %.0f" % (
+    if not (prof[6] and not prof[9]): print("  token pass detail (cycles/packet): loop top %.0f | insert + dup sets %.0f | compare loads + wait %.0f | walk %.0f | publish %.0f | finish block %.0f" % (
         prof[6] / pk, prof[7] / pk, prof[8] / pk, prof[9] / pk, prof[12] / pk, prof[13] / pk))
     sys.exit(0)
 names = ["loop top", "hash+probe issue", "emit prev group", "readback+dup loop", "wait cand load", "info VALU", "walk", "repair+pack", "wait wnext"]
