@@ -818,6 +818,21 @@ def test_extended_levels_in_batches(gpu, oracle, corpus):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 16, 19, 31, 32, 33, 64, 100, 117, 118, 119, 128, 200, 255, 256])
+def test_code_length_runs_of_every_shape(gpu, oracle, k):
+    """The run-length records of the code lengths (huffman.cpp:158-216) are written a lane per run from closed forms
+    (zz_level2.h rle_lengths_w; tests/test_rle_closed_form.py checks the forms on the CPU): bytes uniform over an alphabet of k
+    consecutive values give the literal code runs of k equal non-zero lengths (every remainder of (k - 1) / 6), a run of 256 - k
+    zeros behind them (longer than 138 for small k, 3..10 and 11.. for large), and runs that cross the 64-symbol blocks the wave
+    works in; with the alphabet at the top of the byte range the zero run comes first."""
+    import random
+    rnd = random.Random(1000 + k)
+    for base in (0, 256 - k):
+        d = bytes(base + rnd.randrange(k) for _ in range(40000))
+        for lvl in (2, 3):
+            assert gpu.encode(d, 0, lvl) == oracle.encode_packets(d, 0, lvl, 32768), (k, base, lvl)
+
+
 @pytest.mark.parametrize("lvl", LEVELS)
 def test_shards_concatenate_to_the_whole_stream(gpu, oracle, corpus, lvl):
     """Multi-GPU contract on one GPU: shards cut at packet boundaries + checksum combine == one call."""
