@@ -50,12 +50,38 @@ __host__ __device__ inline uint32_t adler_combine(uint32_t first, uint32_t secon
 // ---- Adler-32 partial of one packet, one wavefront ----------------------------------------------------
 // Returns (a, b) for start value 0: a = sum d_i, b = sum (len - i) d_i, both mod 65521. 16 bytes per lane
 // per step, coalesced; len <= 32768 so 64-bit accumulators cannot overflow.
+#ifndef ZZ_ADLER_INFLIGHT
+#define ZZ_ADLER_INFLIGHT 4      // 16-byte loads a lane has in flight (the packet kernels sum a packet on ONE wavefront in front of its first block)
+#endif
 __device__ __forceinline__ zz_cks wave_adler(const uint8_t* p, uint32_t len)
 {
     const int lane = lane_id();
     uint32_t A = 0;
     uint64_t C = 0;  // sum i * d_i
     const uint32_t nchunks = len >> 4;
+#if ZZ_ADLER_INFLIGHT > 1
+    // U loads in flight per lane (one at a time left the wavefront waiting out 32 memory latencies per 32 KiB packet), and the sums by
+    // v_dot4_u32_u8: a chunk's byte sum is four dot products with ones, its sum k b_k (k = 0..15) four with the weights 0..15
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += ZZ_WAVE * ZZ_ADLER_INFLIGHT) {
+        uint4 v[ZZ_ADLER_INFLIGHT];
+#pragma unroll
+        for (int u = 0; u < ZZ_ADLER_INFLIGHT; ++u) {
+            const uint32_t c = c0 + (uint32_t)u * ZZ_WAVE + (uint32_t)lane;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (c < nchunks) __builtin_memcpy(&v[u], p + ((uint64_t)c << 4), 16);
+        }
+#pragma unroll
+        for (int u = 0; u < ZZ_ADLER_INFLIGHT; ++u) {
+            const uint32_t c = c0 + (uint32_t)u * ZZ_WAVE + (uint32_t)lane;      // (a chunk beyond the end is all zeros: adds nothing)
+            const uint32_t s = __builtin_amdgcn_udot4(v[u].x, 0x01010101u, __builtin_amdgcn_udot4(v[u].y, 0x01010101u,
+                               __builtin_amdgcn_udot4(v[u].z, 0x01010101u, __builtin_amdgcn_udot4(v[u].w, 0x01010101u, 0u, false), false), false), false);
+            const uint32_t t = __builtin_amdgcn_udot4(v[u].x, 0x03020100u, __builtin_amdgcn_udot4(v[u].y, 0x07060504u,
+                               __builtin_amdgcn_udot4(v[u].z, 0x0B0A0908u, __builtin_amdgcn_udot4(v[u].w, 0x0F0E0D0Cu, 0u, false), false), false), false);
+            A += s;
+            C += (uint64_t)(c << 4) * s + t;
+        }
+    }
+#else
     for (uint32_t c = lane; c < nchunks; c += ZZ_WAVE) {
         uint4 v;
         __builtin_memcpy(&v, p + ((uint64_t)c << 4), 16);
@@ -68,6 +94,7 @@ __device__ __forceinline__ zz_cks wave_adler(const uint8_t* p, uint32_t len)
         A += s;
         C += (uint64_t)(c << 4) * s + t;
     }
+#endif
     uint32_t i = (nchunks << 4) + lane;
     if (i < len) {
         uint32_t d = p[i];
