@@ -5,7 +5,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-lib = os.path.join(ROOT, "abl", "prof.so")            # built in the build container (tools/mkab.sh prof -DZZ_PROF) ...
+lib = os.environ.get("ZZ_PROF_LIB") or os.path.join(ROOT, "abl", "prof.so")            # built in the build container (tools/mkab.sh prof -DZZ_PROF) ...
 if not os.path.exists(lib):                            # ... or here
   lib = os.path.join(ROOT, "gpurun_out", "libzz_prof.so")
   os.makedirs(os.path.dirname(lib), exist_ok=True)
@@ -52,3 +52,7 @@ for i, nm in zip(idx, names):
     print(f"  {nm:36s} {100.0 * p1[i] / max(1, tot1):6.2f} %   {p1[i] / b1:8.0f} cyc/block")
 e = list(sets[32:48]); be = max(1, e[10])
 print(f"emitter: blocks {e[10]}; per block: asleep in the barrier {e[0] / be:.0f} cyc, emitting {e[1] / be:.0f} cyc")
+if e[11]:      # per packet (stamps around the emitter's packet: what happens outside the block loop)
+    pk = e[11]
+    print(f"emitter, per packet ({pk} packets): launch to the table-clear barrier {e[2] / pk:.0f} | Adler-32 {e[3] / pk:.0f} | header + wait for the parsers' first probe (B_0) {e[4] / pk:.0f} | "
+          f"B_1 {e[5] / pk:.0f} | the block loop {(e[0] + e[1]) / pk:.0f} | end of block, alignment, flush {e[6] / pk:.0f} cycles")

@@ -109,6 +109,38 @@ __device__ __forceinline__ zz_cks wave_adler(const uint8_t* p, uint32_t len)
     return r;
 }
 
+// One wavefront's share of a packet's sums when `nparts` wavefronts split it: the 1 KiB rows r * nparts + part (64 chunks of 16 bytes, one
+// per lane), U loads in flight; the bytes behind the last whole chunk go to the last part. Raw sums: A = sum d, C = sum i d_i.
+template <int U>
+__device__ __forceinline__ void wave_adler_part(const uint8_t* p, uint32_t len, uint32_t part, uint32_t nparts, uint32_t& A, uint64_t& C)
+{
+    const int lane = lane_id();
+    const uint32_t nchunks = len >> 4;
+    for (uint32_t r0 = 0; (r0 * nparts + part) * ZZ_WAVE < nchunks; r0 += U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = ((r0 + (uint32_t)u) * nparts + part) * ZZ_WAVE + (uint32_t)lane;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (c < nchunks) __builtin_memcpy(&v[u], p + ((uint64_t)c << 4), 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = ((r0 + (uint32_t)u) * nparts + part) * ZZ_WAVE + (uint32_t)lane;
+            const uint32_t s = __builtin_amdgcn_udot4(v[u].x, 0x01010101u, __builtin_amdgcn_udot4(v[u].y, 0x01010101u,
+                               __builtin_amdgcn_udot4(v[u].z, 0x01010101u, __builtin_amdgcn_udot4(v[u].w, 0x01010101u, 0u, false), false), false), false);
+            const uint32_t t = __builtin_amdgcn_udot4(v[u].x, 0x03020100u, __builtin_amdgcn_udot4(v[u].y, 0x07060504u,
+                               __builtin_amdgcn_udot4(v[u].z, 0x0B0A0908u, __builtin_amdgcn_udot4(v[u].w, 0x0F0E0D0Cu, 0u, false), false), false), false);
+            A += s;
+            C += (uint64_t)(c << 4) * s + t;
+        }
+    }
+    if (part == nparts - 1) {
+        const uint32_t i = (nchunks << 4) + (uint32_t)lane;
+        if (i < len) { const uint32_t d = p[i]; A += d; C += (uint64_t)i * d; }
+    }
+}
+
 // ---- Adler-32 per chunk as its own kernel (only the sequential-stream mode needs it: the packet kernels fuse it)
 __global__ __launch_bounds__(ZZ_WAVE) void k_adler_packets(zz_packet_params P)
 {

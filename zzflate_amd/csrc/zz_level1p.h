@@ -74,6 +74,12 @@ namespace zz {
 #define ZZ_L1P_EXT32 0
 #endif
 // the emitter's completed words leave the bit ring in batches of 32..64 (zz_emit.h ring_append_lazy) instead of after every block
+#ifndef ZZ_L1P_ADLER3
+#define ZZ_L1P_ADLER3 1          // cold packets: the Adler-32 sums in three parts, one per wavefront, in front of the first barrier (0: the emitter alone, behind it)
+#endif
+#ifndef ZZ_L1P_ADLER_U
+#define ZZ_L1P_ADLER_U 6        // ... with this many 16-byte loads in flight per lane
+#endif
 #ifndef ZZ_L1P_LAZY_FLUSH
 #define ZZ_L1P_LAZY_FLUSH 1
 #endif
@@ -490,6 +496,15 @@ __device__ __forceinline__ void l1p_packet_parser(const zz_packet_params& P, uin
     if (pw == 0) X->scal[lane] = 0;                                      // block 0: nothing carried in
     if (pw == 0) X->told[lane] = 0;                                      // (tag 0: no block's)
     if (pw == 1 && lane == 0) X->win[ZZ_L1P_SELF] = (uint8_t)ZZ_L1P_SELF; // the sentinel (zz_level1p.h, R)
+    if (!BIAS && ZZ_L1P_ADLER3 && P.cks_kind == ZZ_CKS_ADLER) {
+        // a third of the packet's Adler-32 sums (the emitter takes the last third and puts them together behind the barrier): summed by
+        // the emitter alone, the packet began with both parsers waiting for it -- 48 K cycles of a packet's 1.4 M (instrumented)
+        uint32_t A = 0;
+        uint64_t C = 0;
+        wave_adler_part<ZZ_L1P_ADLER_U>(q.src, q.len, pw, 3, A, C);
+        const uint64_t At = wave_sum64(A), Ct = wave_sum64(C);
+        if (lane == 0) { uint64_t* part = (uint64_t*)(tokbuf + ZZ_L1_TOKSLOT) + 2 * pw; part[0] = At; part[1] = Ct; }   // (the second hand-over slot: free until block 1's tokens)
+    }
     if (BIAS) {
         // the warm window: the first parser enters the last P.warm bytes in front of the packet (zz_level1.h warm_prehash: ascending,
         // the LDS's own order leaves the highest position per hash -- checked as it goes) between two barriers, while the emitter
@@ -521,21 +536,42 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
         else ring_append_uniform(ring, bits, nbits);
     };
     if (ZZ_L1P_PRIO_E) __builtin_amdgcn_s_setprio(ZZ_L1P_PRIO_E);
+    ZZ_PROF_DECL                                                         // (diagnostic builds: [2..6] per packet, [0], [1] per block, tools/prof_l1p.py)
     ring_init(ring, ring_words, q.out);
+    const bool adler3 = !BIAS && ZZ_L1P_ADLER3 && P.cks_kind == ZZ_CKS_ADLER;
+    uint64_t At = 0, Ct = 0;
+    if (adler3) {
+        uint32_t A = 0;
+        uint64_t C = 0;
+        wave_adler_part<ZZ_L1P_ADLER_U>(q.src, q.len, 2, 3, A, C);
+        At = wave_sum64(A); Ct = wave_sum64(C);
+    }
     if (BIAS) l1_group_barrier();                                        // B_c
     else l1_group_barrier();                                             // B_z
-    if (P.cks_kind == ZZ_CKS_ADLER) {                                    // while the parsers work on their first blocks (BIAS: on the window)
+    ZZ_T(2);
+    if (adler3) {
+        if (lane == 0) {
+            const uint64_t* part = (const uint64_t*)(tokbuf + ZZ_L1_TOKSLOT);
+            At += part[0] + part[2]; Ct += part[1] + part[3];
+            zz_cks c;
+            c.a = (uint32_t)(At % ZZ_ADLER_MOD);
+            c.b = (uint32_t)(((uint64_t)q.len * At - Ct) % ZZ_ADLER_MOD);
+            P.cks[k] = c;
+        }
+    } else if (P.cks_kind == ZZ_CKS_ADLER) {                             // BIAS: while the first parser enters the window
         zz_cks c = wave_adler(q.src, q.len);
         if (lane == 0) P.cks[k] = c;
     }
+    ZZ_T(3);
     if (BIAS) l1_group_barrier();                                        // B_z
     if (q.n > 0) {
         append_uniform((q.is_final ? 1u : 0u) | (1u << 1), 3);           // StartBlock(FixedHuffman, final): encoder.cpp:143-147,338
         const uint32_t NB = (q.n + ZZ_WAVE - 1) >> 6;
         const lds_u32* slot = (const lds_u32*)tokbuf + lane;
         l1_group_barrier();                                              // B_0
+        ZZ_T(4);
         l1_group_barrier();                                              // B_1
-        ZZ_PROF_DECL
+        ZZ_T(5); ZZ_C(11, 1);
         for (uint32_t g = 0; g < NB; ++g) {
             ZZ_T(1); ZZ_C(10, 1);                                        // (diagnostic builds: [1] = emitting, [0] = asleep in the barrier)
             l1_group_barrier();                                          // B_g+2: block g's tokens are in slot g & 1
@@ -552,7 +588,6 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
 #endif
         }
         append_uniform(0, 7);                                 // EOB: codes_f[256] (encoder.cpp:371)
-        ZZ_PROF_FLUSH_W(P, 2);
     }
     if (!q.is_final) {
         // SetLevel(0); AddData(e-1, e): one stored byte = byte alignment (zzflate.cpp:118-120, encoder.cpp:482-502)
@@ -569,6 +604,8 @@ __device__ __forceinline__ void l1p_packet_emitter(const zz_packet_params& P, ui
         P.sizes[k] = bytes;
         if (bytes > P.slot_stride) atomicOr(P.err, ZZ_ERR_SLOT_OVERFLOW);
     }
+    ZZ_T(6);
+    ZZ_PROF_FLUSH_W(P, 2);
 }
 
 __global__ __launch_bounds__(ZZ_L1P_THREADS) void k_encode_l1p(zz_packet_params P)
