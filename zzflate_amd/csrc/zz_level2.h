@@ -39,7 +39,8 @@ namespace zz {
 #define ZZ_L2_MAX_TOKENS 8192                       // every match covers >= 4 bytes of a <= 32768-byte packet
 // per resident workgroup: matches as u32 (length symbol - 257 [27:23], length extra value [22:18], distance code
 // [17:13], distance extra value [12:0]), records as u16 (literal byte | ZZ_L2_REC_MATCH)
-#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 4 + ZZ_MAX_PACKET * 2)
+#define ZZ_L2_SNAP_WORDS 164u     // a snapshot of the packed symbol counters [0, 158), then [158] the matches among the records so far, [159] the records, [160] the matches that have arrived
+#define ZZ_L2_SCRATCH_BYTES (ZZ_L2_MAX_TOKENS * 4 + ZZ_MAX_PACKET * 2 + 2 * ZZ_L2_SNAP_WORDS * 4 + 768)
 #define ZZ_L2_REC_MATCH 0x100u
 #define ZZ_L2_REC_NONE 0x200u
 #define ZZ_L2_WIN 16                                // bitmap window, words of 64 positions (11 are live at a time)
@@ -58,7 +59,7 @@ __device__ __forceinline__ void hist_add(uint32_t* histP, uint32_t idx) { atomic
 
 // One finished block of 64 positions -> records + literal counts; frees its window slot. `byte` = src[64F + lane].
 __device__ __forceinline__ uint32_t l2_finish_block(uint64_t* covw, uint64_t* mstw, uint32_t* histP, uint16_t* recs,
-                                                    uint32_t nrec, uint32_t F, uint32_t n, uint32_t byte)
+                                                    uint32_t nrec, uint32_t F, uint32_t n, uint32_t byte, uint32_t* nmatch = nullptr)
 {
     const int lane = lane_id();
     const uint32_t s = F & (ZZ_L2_WIN - 1);
@@ -69,6 +70,7 @@ __device__ __forceinline__ uint32_t l2_finish_block(uint64_t* covw, uint64_t* ms
     const bool lit = p < n && !((cw >> lane) & 1);
     const bool ms = p < n && ((mw >> lane) & 1);
     const uint64_t live = ballot(lit || ms);
+    if (nmatch) *nmatch += (uint32_t)__builtin_popcountll(ballot(ms));
     if (lit) hist_add(histP, byte);
     if (lit || ms) recs[nrec + mbcnt(live)] = (uint16_t)(ms ? ZZ_L2_REC_MATCH : byte);
     return nrec + (uint32_t)__builtin_popcountll(live);
@@ -1157,6 +1159,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
     uint8_t* const my_scratch = Q.scratch + (uint64_t)blockIdx.x * ZZ_L2_SCRATCH_BYTES;
     uint32_t* tokens = (uint32_t*)my_scratch;                                   // matches in stream order
     uint16_t* recs = (uint16_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 4);            // records in stream order
+    uint32_t* snap = (uint32_t*)(my_scratch + ZZ_L2_MAX_TOKENS * 4 + ZZ_MAX_PACKET * 2);   // PP: the counters at the two places the body is cut (l2p_helper_pass)
 
     // Persistent workgroups: the first packet is the workgroup's index, every further one comes from a counter, so
     // that packets of unequal cost (stored fallback vs. dynamic block) do not leave workgroups idle at the end.
@@ -1236,7 +1239,7 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             if (!W0 && !PB) {
                 uint32_t nb = 0, adA = 0;
                 uint64_t adC = 0;
-                const uint32_t nt = PP ? l2p_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, xb, P.err, P.prof)
+                const uint32_t nt = PP ? l2p_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, xb, P.err, snap, P.prof)
                                        : l2_helper_pass(hb, covw, mstw, histP, tokens, recs, src, n, nb, adA, adC, XD ? l6_trips(n) : l2_probe_blocks(n));
                 if (lane == 0) { covw[0] = ((uint64_t)nt << 32) | nb; }       // the window is dead now
                 if (P.cks_kind == ZZ_CKS_ADLER) {
@@ -1275,7 +1278,10 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                 if (uniform(share[0]) == 2) {
                     const uint32_t nbody = (uint32_t)covw[0], r2 = uniform(share[5]);
                     uint32_t m2 = 0;
-                    const uint32_t bits2 = l2_count_bits(recs, tokens, codes, dcodes, r2, m2);
+                    const uint32_t* const cut = misc + 48;
+                    const bool known = uniform(cut[4]) != 0;
+                    if (known) m2 = uniform(cut[3]);
+                    const uint32_t bits2 = known ? uniform(cut[1]) : l2_count_bits(recs, tokens, codes, dcodes, r2, m2);
                     bitring ring3;
                     ring_init_at(ring3, (uint32_t*)(lds + RING3), out, uniform(share[2]) + bits2, share + 7);
                     l2_emit_records(ring3, recs, tokens, codes, dcodes, r2, nbody, m2);
@@ -1316,7 +1322,10 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
                     // place in the bit stream follows from a dry run over the first part.
                     const uint32_t nbody = (uint32_t)covw[0], r1 = uniform(share[1]);
                     uint32_t m1 = 0;
-                    const uint32_t bits1 = l2_count_bits(recs, tokens, codes, dcodes, r1, m1);
+                    const uint32_t* const cut = misc + 48;
+                    const bool known = PP && uniform(cut[4]) != 0;
+                    if (known) m1 = uniform(cut[2]);
+                    const uint32_t bits1 = known ? uniform(cut[0]) : l2_count_bits(recs, tokens, codes, dcodes, r1, m1);
                     bitring ring2;
                     ring_init_at(ring2, (uint32_t*)(lds + RING2), out, uniform(share[2]) + bits1, share + 4);
                     if (PP) {
@@ -1474,9 +1483,36 @@ __global__ __launch_bounds__(PP ? ZZ_L2P_THREADS : ZZ_L2_THREADS, PP ? ZZ_L2P_WP
             {
                 // (two parts: a little more than half here, the helper also has a dry run to do; PP: three parts, each later one with
                 // a longer dry run in front of it)
-                const uint32_t r1 = PP ? ((nbody * ZZ_L2P_SPLIT1) >> 6) & ~63u : ((nbody * ZZ_L2_SPLIT64) >> 6) & ~63u;
+                uint32_t r1 = PP ? ((nbody * ZZ_L2P_SPLIT1) >> 6) & ~63u : ((nbody * ZZ_L2_SPLIT64) >> 6) & ~63u;
                 uint32_t r2 = ((nbody * ZZ_L2P_SPLIT2) >> 6) & ~63u;
                 if (r2 < r1) r2 = r1;
+                uint32_t* const cut = misc + 48;     // PP: [0], [1] bits of the records in front of the second / third part, [2], [3] matches among them, [4] 1 = all of this is known
+                if (PP && l2p_cut(n, 1) != 0xFFFFFFFFu) {
+                    // the body was cut by blocks (l2p_helper_pass): the records in front of a cut are worth sum count x (code length +
+                    // extra bits) over the symbols as counted there (CountBits' sum, :178-187) -- no dry run over them
+                    uint32_t b1 = 0, b2 = 0;
+                    auto cnt = [&](const uint32_t* sp, int j) -> uint32_t { return (sp[j >> 1] >> ((j & 1) << 4)) & 0xFFFFu; };
+                    for (int i = lane; i < 286; i += ZZ_WAVE) {
+                        const uint32_t w = lens[i] + (i < 265 || i == 285 ? 0u : (uint32_t)(i - 261) >> 2);
+                        b1 += cnt(snap, i) * w; b2 += cnt(snap + ZZ_L2_SNAP_WORDS, i) * w;
+                    }
+                    if (lane < 30) {
+                        const uint32_t w = lens[288 + lane] + (lane < 4 ? 0u : (uint32_t)(lane - 2) >> 1);
+                        b1 += cnt(snap, 286 + lane) * w; b2 += cnt(snap + ZZ_L2_SNAP_WORDS, 286 + lane) * w;
+                    }
+                    // ... less the matches that had arrived but start behind the cut (a match may begin up to 258 bytes in front of the block it
+                    // was found in: the counters are read when the block in front of the cut is final, five blocks on): a few dozen tokens
+                    const uint32_t m1 = snap[158], t1 = snap[160], m2 = snap[ZZ_L2_SNAP_WORDS + 158], t2 = snap[ZZ_L2_SNAP_WORDS + 160];
+                    auto tokbits = [&](uint32_t t) -> uint32_t {
+                        const uint32_t ls = t >> 23, bucket = (t >> 13) & 31;
+                        return lens[257 + ls] + ((ls < 8 || ls == 28) ? 0u : (ls - 4) >> 2) + lens[288 + bucket] + (bucket < 4 ? 0u : (bucket - 2) >> 1);
+                    };
+                    for (uint32_t j = m1 + (uint32_t)lane; j < t1; j += ZZ_WAVE) b1 -= tokbits(tokens[j]);
+                    for (uint32_t j = m2 + (uint32_t)lane; j < t2; j += ZZ_WAVE) b2 -= tokbits(tokens[j]);
+                    b1 = wave_sum(b1); b2 = wave_sum(b2);
+                    r1 = snap[159]; r2 = snap[ZZ_L2_SNAP_WORDS + 159];
+                    if (lane == 0) { cut[0] = b1; cut[1] = b2; cut[2] = m1; cut[3] = m2; cut[4] = 1; }
+                } else if (PP && lane == 0) cut[4] = 0;
                 if (lane == 0) { share[0] = 2; share[1] = r1; share[2] = ring.bitpos; if (PP) { share[4] = 0; share[5] = r2; share[7] = 0; } }
                 __syncthreads();             // (X)
                 l2_emit_records(ring, recs, tokens, codes, dcodes, 0, r1, 0);

@@ -586,10 +586,21 @@ __device__ __forceinline__ void l2p_token_pass(uint16_t* T, uint32_t* hb, uint32
 
 // The helper wavefront's side: per block the parsers' match words go to the packet's scratch and into the symbol counts, and the
 // block that can no longer change is turned into records (zz_level2.h, l2_helper_pass: everything else is the walker's now).
+#ifndef ZZ_L2P_SNAP
+#define ZZ_L2P_SNAP 1            // the body cut for its three emitters by BLOCKS, the bits in front of a part from the symbol counters as they stood there (0: by records, a dry run each)
+#endif
+static_assert(!(ZZ_L2P_SNAP && ZZ_L2P_HIST_W), "the snapshots are taken where the helper counts the match symbols");
+// the first block of the body's second (which = 1) and third (2) part; no such cut (0xFFFFFFFF) for packets of fewer than 16 probed blocks
+__device__ __forceinline__ uint32_t l2p_cut(uint32_t n, uint32_t which)
+{
+    const uint32_t target = n > ZZ_MAX_LEN ? n - ZZ_MAX_LEN : 0, trips = (target + 63) >> 6;      // (l2_probe_blocks)
+    if (!ZZ_L2P_SNAP || trips < 16u) return 0xFFFFFFFFu;
+    return (which * ((n + 63u) >> 6)) / 3u;
+}
 __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t* covw, uint64_t* mstw, uint32_t* histP,
                                                     uint32_t* tokens, uint16_t* recs, const uint8_t* src, uint32_t n,
                                                     uint32_t& nrec_out, uint32_t& adA, uint64_t& adC, uint32_t* xb, uint32_t* err,
-                                                    unsigned long long* prof = nullptr)
+                                                    uint32_t* snap, unsigned long long* prof = nullptr)
 {
     l2p_sync* const S = (l2p_sync*)xb;
     (void)S; (void)err;
@@ -600,6 +611,20 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
     const uint32_t gs = l2p_switch_block(target);
     uint32_t nrec = 0, Fnext = 0, ntok = 0;
     adA = 0; adC = 0;
+    // Where the body is cut for its three emitters (ZZ_L2P_SNAP): in front of the blocks F1 and F2, a third and two thirds of the way.
+    // When the block in front of a cut is final the symbol counters go to scratch as they stand, with the number of records, of
+    // matches among them and of matches that have arrived: with the code lengths they give the bits in front of the cut without a
+    // dry run over its records -- less the few matches that have arrived but begin behind it (zz_level2.h).
+    const uint32_t F1 = l2p_cut(n, 1), F2 = l2p_cut(n, 2);
+    uint32_t nmrec = 0;                                                  // matches among the records so far
+    auto snap_counters = [&](uint32_t finished) {
+        if (finished == F1 || finished == F2) {
+            uint32_t* sp = snap + (finished == F1 ? 0u : ZZ_L2_SNAP_WORDS);
+            sp[lane] = histP[lane]; sp[64 + lane] = histP[64 + lane];             // symbols 0 .. 255, two to a word
+            if (lane < 30) sp[128 + lane] = histP[128 + lane];                    // 256 .. 315: lengths and distances of every match that has ARRIVED
+            if (lane == 0) { sp[158] = nmrec; sp[159] = nrec; sp[160] = ntok; }
+        }
+    };
     __builtin_amdgcn_s_setprio(ZZ_L2P_PRIO_H);                           // (down from the code construction's 3 of the packet before)
 #if !ZZ_L2P_FLAGS
     l2_block_barrier();                                                  // B0
@@ -640,8 +665,9 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
         // later matches start at >= base + 64 - 258: block (base>>6) - 5 cannot change any more
         if (i >= ZZ_L2_LAG) {
             ZZ_WAVE_SYNC();
-            nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, fbyte);
+            nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, fbyte, &nmrec);
             Fnext++;
+            snap_counters(Fnext);
         }
     }
     ZZ_WAVE_SYNC();
@@ -649,7 +675,8 @@ __device__ __forceinline__ uint32_t l2p_helper_pass(const uint32_t* hb, uint64_t
         const uint32_t p = (Fnext << 6) + (uint32_t)lane;
         const uint32_t d = p < n ? src[p] : 0u;
         adA += d; adC += (uint64_t)p * d;
-        nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, d);
+        nrec = l2_finish_block(covw, mstw, histP, recs, nrec, Fnext, n, d, &nmrec);
+        snap_counters(Fnext + 1);
     }
     nrec_out = nrec;
 #ifdef ZZ_PROF
