@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t l6_trips(uint32_t n) { return (l6_target(n) 
 //        earlier positions stand in the array since the barrier before, later ones land behind them or in other buckets -- to
 //        the workgroup's scratch in global memory (2*DEPTH bytes per position, coalesced);
 //   3  the array is dead: the window and the packet (<= 64 KiB) take its place in LDS, and all 16 wavefronts compare -- per
-//      position 16 bytes against 16 bytes at each candidate, gathered from LDS (three 8-byte reads and a funnel shift each; from
+//      position 16 bytes against 16 bytes at each candidate, gathered from LDS (three or five words and a funnel shift each; from
 //      global memory every candidate was a 128-byte line for 16 bytes of it, and the load path, not the CU, set the pace);
 //      best of the chain, the lazy rule inside the block, one word per position.
 // m[q] = length << 16 | distance for a position that starts a match if the parse reaches it, 0 otherwise.
@@ -91,8 +91,32 @@ __device__ __forceinline__ void lds_gather16(zz_lds_bytes base, uint32_t off, ui
 
 // the same in two steps, for a candidate: most differ from the position within their first eight bytes, and the third read
 // and half of the shifting are only for those that do not. Returns the number of equal leading bytes, 16 = all.
+// ZZ_L6_WORDS4 = 1 (default): the candidate's words are read at FOUR-byte alignment (ds_read2_b32 + ds_read_b32, then ds_read2_b32), so
+// the five selects between the halves of 8-byte words go: the compare step is bound by the vector ALUs' issue rate (about 22 of
+// their instructions per candidate; reading LESS from the LDS -- a four-byte filter in front, no reads behind a full sixteen -- was
+// slower, fewer instructions is faster: profiles/r05_ab_l6_*.txt). 0 = round 3's form, two or three aligned 8-byte reads.
+#ifndef ZZ_L6_WORDS4
+#define ZZ_L6_WORDS4 1
+#endif
 __device__ __forceinline__ uint32_t lds_match16(zz_lds_bytes base, uint32_t off, uint64_t w, uint64_t w2)
 {
+#if ZZ_L6_WORDS4
+    typedef __attribute__((address_space(3))) const uint32_t* p4;
+    const p4 p = (p4)(base + (off & ~3u));
+    const uint32_t sh = (off & 3u) << 3;
+    const uint32_t e0 = p[0], e1 = p[1], e2 = p[2];
+    const uint32_t d0 = __builtin_amdgcn_alignbit(e1, e0, sh) ^ (uint32_t)w, d1 = __builtin_amdgcn_alignbit(e2, e1, sh) ^ (uint32_t)(w >> 32);
+    const uint32_t f0 = ffbl_or_ones(d0), f1 = add_sat_k<32>(ffbl_or_ones(d1));
+    uint32_t bits = f0 < f1 ? f0 : f1;                                   // >= 64: the first eight bytes are equal
+    if (bits >= 64u) {
+        const uint32_t e3 = p[3], e4 = p[4];
+        const uint32_t d2 = __builtin_amdgcn_alignbit(e3, e2, sh) ^ (uint32_t)w2, d3 = __builtin_amdgcn_alignbit(e4, e3, sh) ^ (uint32_t)(w2 >> 32);
+        const uint32_t f2 = ffbl_or_ones(d2), f3 = add_sat_k<32>(ffbl_or_ones(d3));
+        const uint32_t t = f2 < f3 ? f2 : f3;
+        bits = 64u + (t < 64u ? t : 64u);
+    }
+    return bits >> 3;
+#else
     typedef __attribute__((address_space(3))) const uint64_t* p8;
     const uint32_t a = off & ~7u, sh = (off & 3u) << 3;
     const bool up = (off & 4u) != 0;
@@ -112,6 +136,7 @@ __device__ __forceinline__ uint32_t lds_match16(zz_lds_bytes base, uint32_t off,
         bits = 64u + (t < 64u ? t : 64u);
     }
     return bits >> 3;
+#endif
 }
 
 template <int DEPTH>
@@ -321,8 +346,8 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {                               // i = 0: the nearest
                         const uint32_t co = c[DEPTH - 1 - i];                      // the candidate's offset in the image
-                        const uint32_t d = (ZZ_L6_BIAS + q) - co;                   // 0 < d < 32768: a candidate
-                        if (act && (d - 1u) < 32767u) {
+                        const uint32_t d = (ZZ_L6_BIAS + q) - co;                   // 0 < d < 32768: a candidate (d != 0: the entries
+                        if (act && d < 32768u) {                                    // in front of q's place are other positions)
                             const uint32_t ln = lds_match16(L, co, w, w2);
                             if (ln > best) { best = ln; bdist = d; }
                         }
