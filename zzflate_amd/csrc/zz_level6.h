@@ -98,9 +98,33 @@ __device__ __forceinline__ void lds_gather16(zz_lds_bytes base, uint32_t off, ui
 #ifndef ZZ_L6_WORDS4
 #define ZZ_L6_WORDS4 1
 #endif
+// ZZ_L6_WORDS4 = 2: ONE byte-addressed ds_read_b64 per eight bytes and no funnel shifts (three vector instructions fewer per candidate):
+// bit-exact and 22 % SLOWER at level 6 (43.0 -> 33.5 GB/s): the LDS serves a misaligned 8-byte read at a fraction of an aligned one's rate
+// (profiles/r05_ab_l6_unaligned_reads_and_packed_key.txt). ZZ_L6_KEY = 1 (default): the chain's best as ONE max over
+// length << 16 | 32767 - distance instead of compare + max + select: + 0.4 %.
+#ifndef ZZ_L6_KEY
+#define ZZ_L6_KEY 1
+#endif
 __device__ __forceinline__ uint32_t lds_match16(zz_lds_bytes base, uint32_t off, uint64_t w, uint64_t w2)
 {
-#if ZZ_L6_WORDS4
+#if ZZ_L6_WORDS4 == 2
+    // the candidate's bytes by ONE byte-addressed 8-byte LDS read (the LDS serves unaligned reads: the compiler emits ds_read_b64 for an
+    // align-1 access on gfx950), no funnel shifts, no address arithmetic
+    typedef uint64_t __attribute__((aligned(1))) u64u;
+    typedef __attribute__((address_space(3))) const u64u* p8u;
+    const uint64_t x = *(p8u)(base + off);
+    const uint32_t d0 = (uint32_t)x ^ (uint32_t)w, d1 = (uint32_t)(x >> 32) ^ (uint32_t)(w >> 32);
+    const uint32_t f0 = ffbl_or_ones(d0), f1 = add_sat_k<32>(ffbl_or_ones(d1));
+    uint32_t bits = f0 < f1 ? f0 : f1;                                   // >= 64: the first eight bytes are equal
+    if (bits >= 64u) {
+        const uint64_t y = *(p8u)(base + off + 8u);
+        const uint32_t d2 = (uint32_t)y ^ (uint32_t)w2, d3 = (uint32_t)(y >> 32) ^ (uint32_t)(w2 >> 32);
+        const uint32_t f2 = ffbl_or_ones(d2), f3 = add_sat_k<32>(ffbl_or_ones(d3));
+        const uint32_t t = f2 < f3 ? f2 : f3;
+        bits = 64u + (t < 64u ? t : 64u);
+    }
+    return bits >> 3;
+#elif ZZ_L6_WORDS4
     typedef __attribute__((address_space(3))) const uint32_t* p4;
     const p4 p = (p4)(base + (off & ~3u));
     const uint32_t sh = (off & 3u) << 3;
@@ -343,6 +367,21 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
                     uint64_t w, w2;
                     lds_gather16(L, ZZ_L6_BIAS + qa, w, w2);                        // q + 16 <= n: inside the data
                     uint32_t best = 0, bdist = 0;
+#if ZZ_L6_KEY
+                    // longest wins, the nearest among equals: one max over length << 16 | 32767 - distance (distances grow along the chain)
+                    uint32_t key = 0;
+                    const uint32_t K = 32767u - (ZZ_L6_BIAS + q);
+#pragma unroll
+                    for (int i = 0; i < DEPTH; ++i) {                               // i = 0: the nearest
+                        const uint32_t co = c[DEPTH - 1 - i];                      // the candidate's offset in the image
+                        const uint32_t e = co + K;                                  // 32767 - d; d < 32768 as below
+                        if (act && e < 32768u) {
+                            const uint32_t k = (lds_match16(L, co, w, w2) << 16) | e;
+                            key = k > key ? k : key;
+                        }
+                    }
+                    best = key >> 16; bdist = 32767u - (key & 0xFFFFu);
+#else
 #pragma unroll
                     for (int i = 0; i < DEPTH; ++i) {                               // i = 0: the nearest
                         const uint32_t co = c[DEPTH - 1 - i];                      // the candidate's offset in the image
@@ -352,6 +391,7 @@ __global__ __launch_bounds__(ZZ_L6M_THREADS) void k_l6_matches(zz_l6m_params Q)
                             if (ln > best) { best = ln; bdist = d; }
                         }
                     }
+#endif
                     if (best < 4) best = 0;
                     // lazy: the next position's length (lane 63 never defers)
                     const uint32_t nxt = (uint32_t)__shfl_down((int)best, 1);
