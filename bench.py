@@ -648,6 +648,12 @@ def main():
                     insts = tj.get(f"instructions_level{args.level}_{args.gen}_{args.mib}MiB")
                     tj_scalar = tj.get(f"scalar_instructions_level{args.level}_{args.gen}_{args.mib}MiB")
                     traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')}"
+                    # the counters were collected on the default (cold, two-parser) kernels: another kernel's line does not borrow them
+                    other = bool(args.warm) or os.environ.get("ZZFLATE_L1_KERNEL") == "classic" or os.environ.get("ZZFLATE_L2_KERNEL") == "classic" \
+                        or (args.level == 1 and hasattr(zz.lib, "zz_debug_l1_kernel") and zz.lib.zz_debug_l1_kernel(ctx._h) != 2)
+                    if other and traffic is not None:
+                        traffic, insts, tj_scalar = None, None, None
+                        traffic_src += " was measured on the default kernel of this level, not on the one this run launched: not reported"
                 else:
                     traffic_src = f"profiles/traffic.json @ {tj.get('git_sha')} is stale (kernel sources changed since): not reported"
             except Exception:
